@@ -1,0 +1,189 @@
+"""Generate tests/golden/*.npz from the REAL reference (survey container only).
+
+Imports /root/reference/src/Ev2Hands/model/{pointnet2_utils,TEHNet}.py as a synthetic package
+(the package __init__ drags in trimesh/pyrender/manopth, which are absent -- SURVEY.md
+Appendix A), loads a synthetic checkpoint with the reference's own `load_state_dict(strict=True)`,
+runs its forward on seeded synthetic clouds and records selections + outputs.  The MANO call is
+served by oracle/mano_oracle.py (manopth and the MANO assets are not available; that part is
+UNPINNED and stored under keys starting with `unpinned.`).
+
+It also asserts that oracle/tehnet_oracle.py reproduces the reference bit-for-bit here, so a
+fixture is only ever written from a state where restatement == reference.
+
+Run:  python oracle/make_golden.py            (needs /root/reference; never runs on the GPU box)
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ev2hands_amd import synth  # noqa: E402
+from oracle import mano_oracle, tehnet_oracle  # noqa: E402
+
+REF_MODEL_DIR = "/root/reference/src/Ev2Hands/model"
+CASES = [
+    # name,            kind, C, N,    B, seed
+    ("U_c4_n2048", "U", 4, 2048, 2, 0),
+    ("E_c5_n2048", "E", 5, 2048, 2, 1),
+    ("U_c5_n256", "U", 5, 256, 2, 2),
+    ("E_c4_n256", "E", 4, 256, 2, 3),
+]
+
+
+def load_reference():
+    pkg = types.ModuleType("refmodel")
+    pkg.__path__ = [REF_MODEL_DIR]
+    sys.modules["refmodel"] = pkg
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(f"refmodel.{name}", f"{REF_MODEL_DIR}/{name}.py")
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[spec.name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    return load("pointnet2_utils"), load("TEHNet")
+
+
+def sample(t: torch.Tensor, stride: int = 97) -> np.ndarray:
+    return t.detach().reshape(-1)[::stride].numpy().copy()
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.abs().max().item(), t.pow(2).mean().sqrt().item()])
+
+
+def run_case(pn, te, name, kind, C, N, B, seed):
+    os.environ["ERPC"] = "1" if C == 5 else "0"
+    sd = synth.synth_state_dict(C, seed)
+    net = te.TEHNet(n_pose_params=synth.MANO_CMPS)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
+    xyz = synth.synth_cloud(kind, B, C, N, seed)
+    inits = synth.fps_inits(B, N, seed)
+
+    # spy on the reference's selections
+    rec = {"fps": [], "ball": [], "nn": []}
+    o_fps, o_ball, o_sq = pn.farthest_point_sample, pn.query_ball_point, pn.square_distance
+    it = iter(inits)
+    o_randint = torch.randint
+
+    def spy_randint(*a, **k):
+        v = next(it)
+        assert a[1] in (N, 512) and tuple(a[2]) == (B,)
+        return v.clone()
+
+    def spy_fps(x, n):
+        r = o_fps(x, n)
+        rec["fps"].append(r.clone())
+        return r
+
+    def spy_ball(r_, k_, x, nx):
+        r = o_ball(r_, k_, x, nx)
+        rec["ball"].append(r.clone())
+        return r
+
+    pn.farthest_point_sample, pn.query_ball_point = spy_fps, spy_ball
+    feats = {}
+    hooks = []
+    for mod_name in ("sa1", "sa2", "sa3", "fp3", "fp2", "fp1", "classifier", "left_query_conv", "right_query_conv"):
+        def mk(nm):
+            def hook(_m, _i, o):
+                feats[nm] = o
+            return hook
+        hooks.append(getattr(net, mod_name).register_forward_hook(mk(mod_name)))
+    for side in ("left", "right"):
+        def mkp(sd_):
+            def hook(_m, i, o):
+                feats[sd_ + ".params"] = o
+            return hook
+        hooks.append(getattr(net, side + "_mano_regressor").mano_regressor.register_forward_hook(mkp(side)))
+        def mkf(sd_):
+            def hook(_m, i):
+                feats[sd_ + ".hand_features"] = i[1]
+            return hook
+        hooks.append(getattr(net, side + "_mano_regressor").register_forward_pre_hook(mkf(side)))
+
+    torch.randint = spy_randint
+    try:
+        with torch.no_grad():
+            ref = net(xyz.clone(), hands)
+    finally:
+        torch.randint = o_randint
+        pn.farthest_point_sample, pn.query_ball_point = o_fps, o_ball
+        for h in hooks:
+            h.remove()
+
+    # our restatement must be identical here
+    trace = {}
+    with torch.no_grad():
+        mine = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=trace)
+    assert torch.equal(mine["class_logits"], ref["class_logits"]), "oracle != reference (logits)"
+    for side in ("left", "right"):
+        for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl"):
+            assert torch.equal(mine[side][k], ref[side][k]), f"oracle != reference ({side}.{k})"
+        assert np.array_equal(mine[side]["faces"], ref[side]["faces"])
+    fps_names = ["sa1.fps", "sa2.fps", "left_mano_regressor.sa1.fps", "right_mano_regressor.sa1.fps"]
+    for nm, r in zip(fps_names, rec["fps"]):
+        assert torch.equal(trace[nm], r), nm
+    ball_names = ([f"sa1.group{i}" for i in range(3)] + [f"sa2.group{i}" for i in range(2)]
+                  + [f"left_mano_regressor.sa1.group{i}" for i in range(2)]
+                  + [f"right_mano_regressor.sa1.group{i}" for i in range(2)])
+    for nm, r in zip(ball_names, rec["ball"]):
+        assert torch.equal(trace[nm], r), nm
+    assert torch.equal(trace["l0_points"], feats["fp1"])
+    assert torch.equal(trace["left.query"], feats["left_query_conv"])
+    assert torch.equal(trace["left.params"], feats["left.params"])
+
+    out = {
+        "meta": np.array([B, C, N, seed], dtype=np.int64),
+        "kind": np.array(kind),
+        "xyz": xyz.numpy(),
+        "fps_init": torch.stack(inits).numpy().astype(np.int32),
+        "class_logits": ref["class_logits"].numpy(),
+        "argmax": ref["class_logits"].argmax(1).numpy().astype(np.uint8),
+    }
+    for nm, r in zip(fps_names, rec["fps"]):
+        out[nm] = r.numpy().astype(np.int16)
+    for nm, r in zip(ball_names, rec["ball"]):
+        out[nm] = r.numpy().astype(np.int16)
+    for nm in ("fp2", "fp1"):
+        out[nm + ".nn_idx"] = trace[nm + ".nn_idx"].numpy().astype(np.int16)
+        out[nm + ".nn_w"] = trace[nm + ".nn_w"].numpy()
+    for nm in ("sa1", "sa2", "sa3"):
+        out[nm + ".feat.stats"] = stats(feats[nm][1])
+        out[nm + ".feat.sample"] = sample(feats[nm][1])
+    out["sa1.new_xyz"] = feats["sa1"][0].numpy()
+    out["sa2.new_xyz"] = feats["sa2"][0].numpy()
+    for nm in ("fp3", "fp2", "fp1", "left_query_conv", "right_query_conv"):
+        out[nm + ".stats"] = stats(feats[nm])
+        out[nm + ".sample"] = sample(feats[nm])
+    for side in ("left", "right"):
+        out[side + ".hand_features"] = feats[side + ".hand_features"].numpy()
+        out[side + ".params"] = feats[side + ".params"].numpy()
+        out[f"unpinned.{side}.vertices"] = ref[side]["vertices"].numpy()
+        out[f"unpinned.{side}.j3d"] = ref[side]["j3d"].numpy()
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def main():
+    torch.set_num_threads(8)
+    pn, te = load_reference()
+    for case in CASES:
+        run_case(pn, te, *case)
+
+
+if __name__ == "__main__":
+    main()
