@@ -1,0 +1,136 @@
+"""ctypes binding of libev2hands_hip.so (include/ev2hands_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or fails to load,
+`lib()` raises.  Build it with `python -m ev2hands_amd.build` (or __graft_entry__.build()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libev2hands_hip.so")
+
+vp = C.c_void_p
+ci = C.c_int
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("X", vp), ("ldx", ci), ("W", vp), ("ldw", ci), ("Y", vp), ("ldy", ci),
+                ("M", ci), ("N", ci), ("K", ci),
+                ("bias", vp), ("bias_group_rows", ci), ("ldbias", ci), ("relu", ci),
+                ("post_scale", vp), ("post_shift", vp),
+                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci)]
+
+
+class SaDesc(C.Structure):
+    _fields_ = [("P1", vp), ("ldp", ci), ("pts4", vp), ("ctr4", vp), ("gidx", vp),
+                ("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
+                ("out", vp), ("ldo", ci),
+                ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
+                ("C1", ci), ("C2", ci), ("C3", ci)]
+
+
+class SaBranch(C.Structure):
+    _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
+                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float)]
+
+
+class SaModule(C.Structure):
+    _fields_ = [("W1f", vp), ("b1", vp), ("kf", ci), ("npoint", ci), ("nbranch", ci), ("br", SaBranch * 3)]
+
+
+class Dense(C.Structure):
+    _fields_ = [("W", vp), ("b", vp), ("post_scale", vp), ("post_shift", vp), ("O", ci), ("K", ci), ("ldw", ci)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("sa1", SaModule), ("sa2", SaModule), ("mano_sa1", SaModule * 2),
+                ("sa3", Dense * 3),
+                ("fp3_skip", Dense), ("fp3_bcast", Dense), ("fp3_1", Dense),
+                ("fp2", Dense * 2), ("fp1", Dense * 3),
+                ("cls0", Dense), ("cls4", Dense),
+                ("qconv0", Dense), ("qconv4", Dense * 2),
+                ("mano_sa2", (Dense * 2) * 2),
+                ("head0", Dense * 2), ("head4", Dense * 2)]
+
+
+class ManoConsts(C.Structure):
+    _fields_ = [("hands_mean", vp), ("comps", vp), ("blend_T", vp), ("v_template", vp),
+                ("J_template", vp), ("J_shape", vp), ("weights", vp),
+                ("tips", C.c_int32 * 5), ("ncomps", C.c_int32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("class_logits", vp), ("params", vp * 2), ("vertices", vp * 2), ("joints", vp * 2)]
+
+
+EXPORTS = [
+    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
+    "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
+    "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max",
+    "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano",
+    "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer",
+]
+
+_lib = None
+
+
+class Ev2hError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Ev2hError(f"{LIB_PATH} is missing: build the HIP library first "
+                        f"(python -m ev2hands_amd.build). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.ev2h_last_error.restype = C.c_char_p
+    L.ev2h_workspace_bytes.restype = C.c_size_t
+    L.ev2h_workspace_bytes.argtypes = [ci, ci]
+    L.ev2h_workspace_buffer.restype = vp
+    L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
+    L.ev2h_struct_sizes.restype = None
+    L.ev2h_struct_sizes.argtypes = [C.c_size_t * 6]
+    L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+    L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+    L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
+    L.ev2h_ball_query.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(vp), vp, vp]
+    L.ev2h_three_nn_interp.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp]
+    L.ev2h_gemm.argtypes = [C.POINTER(GemmDesc), vp]
+    L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, vp]
+    L.ev2h_sa_mlp_max.argtypes = [C.POINTER(SaDesc), vp]
+    L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
+    L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp, vp]
+    L.ev2h_forward.argtypes = [C.POINTER(Weights), C.POINTER(ManoConsts), C.POINTER(ManoConsts), vp, ci, ci, ci, ci, vp,
+                               C.POINTER(Outputs), vp, C.c_size_t, vp]
+    sizes = (C.c_size_t * 6)()
+    L.ev2h_struct_sizes(sizes)
+    mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs)]
+    if list(sizes) != mine:
+        raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
+    if L.ev2h_abi_version() != 1:
+        raise Ev2hError("ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().ev2h_last_error().decode(errors="replace")
+        raise Ev2hError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a torch tensor, 0 for None."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,323 @@
+// ev2h_forward: TEHNet.forward (/root/reference/src/Ev2Hands/model/TEHNet.py:168-197) as one
+// in-order sequence of gfx950 kernels on a caller-provided stream and workspace.  No allocation,
+// no host synchronisation, no device->host copies inside (hipGraph-capturable).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.hpp"
+#include "ev2hands_hip.h"
+
+int ev2h_gemm_init();
+
+// ---------------------------------------------------------------------------------------- errors / init
+static thread_local char g_err[512] = "";
+
+void ev2h_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ev2h_last_error(void) { return g_err; }
+extern "C" int ev2h_abi_version(void) { return EV2H_ABI_VERSION; }
+
+extern "C" void ev2h_struct_sizes(size_t out[6]) {
+    out[0] = sizeof(ev2h_gemm_desc);
+    out[1] = sizeof(ev2h_sa_desc);
+    out[2] = sizeof(ev2h_sa_module);
+    out[3] = sizeof(ev2h_weights);
+    out[4] = sizeof(ev2h_mano_consts);
+    out[5] = sizeof(ev2h_outputs);
+}
+
+extern "C" int ev2h_init(void) {
+    static bool done = false;
+    if (done) return EV2H_OK;
+    int rc = ev2h_gemm_init();
+    if (rc) return rc;
+    done = true;
+    return EV2H_OK;
+}
+
+// ---------------------------------------------------------------------------------------- small kernels
+namespace {
+
+// dst[row][col..col+7] = (x, y, z, 0, 0, 0, 0, 0): the raw-xyz columns of a group-all input
+// (pointnet2_utils.py:155 concatenates [xyz, features]; our packed weights use [features | xyz | pad]).
+__global__ __launch_bounds__(256) void write_xyz_cols_kernel(const float4* __restrict__ src4, size_t rows, float* __restrict__ dst,
+                                                             int ld, int col) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float4 v = src4[r];
+    float4* o = reinterpret_cast<float4*>(dst + r * ld + col);
+    o[0] = make_float4(v.x, v.y, v.z, 0.f);
+    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------- workspace layout
+struct Buf {
+    const char* name;
+    size_t off;     // bytes
+    size_t count;   // elements (4 bytes each)
+};
+
+struct Layout {
+    static constexpr int MAXB = 96;
+    Buf bufs[MAXB];
+    int n = 0;
+    size_t total = 0;
+    size_t add(const char* name, size_t count) {
+        const size_t off = total;
+        bufs[n++] = Buf{name, off, count};
+        total += (count * 4 + 255) / 256 * 256;
+        return off;
+    }
+    const Buf* find(const char* name) const {
+        for (int i = 0; i < n; ++i)
+            if (!strcmp(bufs[i].name, name)) return &bufs[i];
+        return nullptr;
+    }
+};
+
+static const char* hname(const char* base, int h) {
+    static thread_local char pool[32][24];
+    static thread_local int cur = 0;
+    char* s = pool[cur++ & 31];
+    snprintf(s, 24, "%s%c", base, h ? 'R' : 'L');
+    return s;
+}
+
+// names with an L/R suffix are stored as literals so Buf::name stays valid
+static const char* const kHandNames[2][10] = {
+    {"P1mL", "fpsmL", "ctrmL", "gidxm0L", "gidxm1L", "cntmL", "m1bufL", "msa2hL", "m2L", "fc1L"},
+    {"P1mR", "fpsmR", "ctrmR", "gidxm0R", "gidxm1R", "cntmR", "m1bufR", "msa2hR", "m2R", "fc1R"}};
+
+static void build_layout(Layout& L, int B, int N) {
+    const size_t R = (size_t)B * N;
+    const size_t b = (size_t)B;
+    L.add("pts4", R * 4);
+    L.add("feat8", R * 8);
+    L.add("fps1", b * 512);
+    L.add("ctr1", b * 512 * 4);
+    L.add("P1a", R * 160);
+    L.add("gidx1_0", b * 512 * 32);
+    L.add("gidx1_1", b * 512 * 64);
+    L.add("gidx1_2", b * 512 * 128);
+    L.add("cnt1", b * 512 * 3);
+    L.add("l1cat", b * 512 * 576);
+    L.add("P1b", b * 512 * 256);
+    L.add("fps2", b * 128);
+    L.add("ctr2", b * 128 * 4);
+    L.add("gidx2_0", b * 128 * 64);
+    L.add("gidx2_1", b * 128 * 128);
+    L.add("cnt2", b * 128 * 2);
+    L.add("l2buf", b * 128 * 520);
+    L.add("sa3h1", b * 128 * 256);
+    L.add("sa3h2", b * 128 * 512);
+    L.add("l3", b * 1024);
+    L.add("fp3bias", b * 256);
+    L.add("fp3h", b * 128 * 256);
+    L.add("fp3o", b * 128 * 256);
+    L.add("fp2h", b * 512 * 256);
+    L.add("l1new", b * 512 * 128);
+    L.add("fp1in", R * 128);
+    L.add("fp1h1", R * 128);
+    L.add("fp1h2", R * 128);
+    L.add("l0", R * 256);
+    L.add("clsh", R * 256);
+    L.add("logits_pm", R * 4);
+    L.add("q1", R * 512);
+    L.add("q2", 2 * R * 256);
+    L.add("sim", b * 2 * 4 * 256);
+    L.add("hf8", 2 * R * 8);
+    L.add("nn2_idx", b * 512 * 3);
+    L.add("nn2_w", b * 512 * 3);
+    L.add("nn1_idx", R * 3);
+    L.add("nn1_w", R * 3);
+    for (int h = 0; h < 2; ++h) {
+        L.add(kHandNames[h][0], R * 256);
+        L.add(kHandNames[h][1], b * 128);
+        L.add(kHandNames[h][2], b * 128 * 4);
+        L.add(kHandNames[h][3], b * 128 * 64);
+        L.add(kHandNames[h][4], b * 128 * 128);
+        L.add(kHandNames[h][5], b * 128 * 2);
+        L.add(kHandNames[h][6], b * 128 * 520);
+        L.add(kHandNames[h][7], b * 128 * 256);
+        L.add(kHandNames[h][8], b * 512);
+        L.add(kHandNames[h][9], b * 1024);
+    }
+    (void)hname;
+}
+
+struct Ws {
+    char* base;
+    Layout L;
+    float* f(const char* name) const { return reinterpret_cast<float*>(base + L.find(name)->off); }
+    int32_t* i(const char* name) const { return reinterpret_cast<int32_t*>(base + L.find(name)->off); }
+};
+
+#define RUN(expr)                 \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__) return rc__;    \
+    } while (0)
+
+static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st,
+                 const float* group_bias = nullptr, int group_rows = 0, int ldbias = 0, int taps = 1, int rows_per_seq = 0,
+                 int rowmax_rows = 0) {
+    ev2h_gemm_desc d{};
+    d.X = X; d.ldx = ldx; d.W = w.W; d.ldw = w.ldw; d.Y = Y; d.ldy = ldy;
+    d.M = M; d.N = w.O; d.K = w.K;
+    d.bias = group_bias ? group_bias : w.b;
+    d.bias_group_rows = group_rows; d.ldbias = ldbias;
+    d.relu = relu; d.post_scale = w.post_scale; d.post_shift = w.post_shift;
+    d.taps = taps; d.rows_per_seq = rows_per_seq; d.rowmax_rows = rowmax_rows;
+    return ev2h_gemm(&d, st);
+}
+
+// one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius
+static int sa_module(const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
+                     int32_t* const* gidx, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st) {
+    int c1sum = 0;
+    for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
+    ev2h_gemm_desc g{};
+    g.X = feat; g.ldx = ldf; g.W = m.W1f; g.ldw = m.kf; g.Y = P1; g.ldy = c1sum;
+    g.M = B * Npts; g.N = c1sum; g.K = m.kf; g.bias = m.b1; g.taps = 1;
+    RUN(ev2h_gemm(&g, st));
+    int coff1 = 0, coff3 = 0;
+    for (int i = 0; i < m.nbranch; ++i) {
+        const ev2h_sa_branch& br = m.br[i];
+        ev2h_sa_desc d{};
+        d.P1 = P1 + coff1; d.ldp = c1sum; d.pts4 = pts4; d.ctr4 = ctr4; d.gidx = gidx[i];
+        d.W1x = br.W1x; d.W2 = br.W2; d.b2 = br.b2; d.W3 = br.W3; d.b3 = br.b3;
+        d.out = out + coff3; d.ldo = ldo;
+        d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
+        RUN(ev2h_sa_mlp_max(&d, st));
+        coff1 += br.C1;
+        coff3 += br.C3;
+    }
+    return EV2H_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ev2h_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    Layout L;
+    build_layout(L, B, N);
+    return L.total;
+}
+
+extern "C" const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count) {
+    if (!workspace || !name || B <= 0 || N <= 0) return nullptr;
+    Layout L;
+    build_layout(L, B, N);
+    const Buf* b = L.find(name);
+    if (!b) return nullptr;
+    if (count) *count = b->count;
+    return static_cast<char*>(workspace) + b->off;
+}
+
+extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
+                            float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
+                            void* workspace, size_t workspace_bytes, ev2h_stream_t st) {
+    EV2H_CHECK_ARG(w && mano_left && mano_right && xyz_cm && fps_init && out && workspace);
+    EV2H_CHECK_ARG(B > 0 && N >= 128 && N <= 8192 && (C == 4 || C == 5));
+    EV2H_CHECK_ARG(out->class_logits && out->params[0] && out->params[1] && out->vertices[0] && out->vertices[1] &&
+                   out->joints[0] && out->joints[1]);
+    EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
+    EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
+    RUN(ev2h_init());
+    Ws ws;
+    ws.base = static_cast<char*>(workspace);
+    build_layout(ws.L, B, N);
+    if (workspace_bytes < ws.L.total) {
+        ev2h_set_error("ev2h_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.L.total);
+        return EV2H_ERR_WORKSPACE;
+    }
+    const int R = B * N;
+    const ev2h_mano_consts* mano[2] = {mano_left, mano_right};
+
+    // ---- input layout + all three samplings of the raw cloud (enc.sa1, left.sa1, right.sa1)
+    RUN(ev2h_prep_points(xyz_cm, B, C, N, mhlnes, ws.f("pts4"), ws.f("feat8"), st));
+    {
+        const int S[3] = {512, 128, 128};
+        const int64_t* init[3] = {fps_init, fps_init + 2 * (size_t)B, fps_init + 3 * (size_t)B};
+        int32_t* idx[3] = {ws.i("fps1"), ws.i("fpsmL"), ws.i("fpsmR")};
+        float* ctr[3] = {ws.f("ctr1"), ws.f("ctrmL"), ws.f("ctrmR")};
+        RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
+    }
+    // ---- enc.sa1 (TEHNet.py:179)
+    {
+        const ev2h_sa_module& m = w->sa1;
+        float rad[3]; int ns[3];
+        int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
+        for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
+        RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
+        RUN(sa_module(m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
+    }
+    // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
+    {
+        const ev2h_sa_module& m = w->sa2;
+        RUN(ev2h_fps(ws.f("ctr1"), B, 512, 128, fps_init + (size_t)B, ws.i("fps2"), ws.f("ctr2"), st));
+        float rad[2]; int ns[2];
+        int32_t* gi[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
+        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
+        RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi, ws.i("cnt2"), st));
+        RUN(sa_module(m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
+        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
+                                                                                   ws.f("l2buf"), 520, 512);
+        EV2H_CHECK_LAUNCH();
+    }
+    // ---- enc.sa3 group-all (TEHNet.py:181): 515 -> 256 -> 512 -> 1024, max over the 128 points
+    RUN(dense(w->sa3[0], ws.f("l2buf"), 520, B * 128, ws.f("sa3h1"), 256, 1, st));
+    RUN(dense(w->sa3[1], ws.f("sa3h1"), 256, B * 128, ws.f("sa3h2"), 512, 1, st));
+    RUN(dense(w->sa3[2], ws.f("sa3h2"), 512, B * 128, ws.f("l3"), 1024, 1, st, nullptr, 0, 0, 1, 0, 128));
+    // ---- fp3 (TEHNet.py:184): the single l3 point is broadcast, so its 1024 inputs collapse to a per-window bias
+    RUN(dense(w->fp3_bcast, ws.f("l3"), 1024, B, ws.f("fp3bias"), 256, 0, st));
+    RUN(dense(w->fp3_skip, ws.f("l2buf"), 520, B * 128, ws.f("fp3h"), 256, 1, st, ws.f("fp3bias"), 128, 256));
+    RUN(dense(w->fp3_1, ws.f("fp3h"), 256, B * 128, ws.f("fp3o"), 256, 1, st));
+    // ---- fp2 (TEHNet.py:185): 3-NN 128 -> 512, concat [skip 320 | interpolated 256]
+    RUN(ev2h_three_nn_interp(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, ws.f("fp3o"), 256, 256, ws.f("l1cat") + 320, 576,
+                             ws.i("nn2_idx"), ws.f("nn2_w"), st));
+    RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st));
+    RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st));
+    // ---- fp1 (TEHNet.py:186): 3-NN 512 -> N, no skip
+    RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
+                             ws.i("nn1_idx"), ws.f("nn1_w"), st));
+    RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st));
+    RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st));
+    RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st));
+    // ---- classifier (TEHNet.py:188)
+    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, st));
+    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, st));
+    RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, st));
+    // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
+    RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, nullptr, 0, 0, 3, N));
+    for (int h = 0; h < 2; ++h)
+        RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, nullptr, 0, 0, 3, N));
+    // ---- attention (TEHNet.py:13-27)
+    RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
+    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), st));
+    // ---- MANO regressors (TEHNet.py:194-195, 68-112)
+    for (int h = 0; h < 2; ++h) {
+        const ev2h_sa_module& m = w->mano_sa1[h];
+        const char* const* nm = kHandNames[h];
+        float rad[2]; int ns[2];
+        int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
+        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
+        RUN(ev2h_ball_query(ws.f("pts4"), ws.f(nm[2]), B, N, 128, 2, rad, ns, gi, ws.i(nm[5]), st));
+        RUN(sa_module(m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, st));
+        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
+                                                                                   ws.f(nm[6]), 520, 512);
+        EV2H_CHECK_LAUNCH();
+        RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, st));
+        RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, st, nullptr, 0, 0, 1, 0, 128));
+        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, st));
+        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, st));
+        RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], st));
+    }
+    return EV2H_OK;
+}

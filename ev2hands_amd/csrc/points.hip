@@ -1,0 +1,335 @@
+// Point-set selection kernels of the Ev2Hands encoder for gfx950:
+//   prep_points      [B,C,N] channel-major input -> point-major xyz(+|p|^2) and zero-padded features
+//   fps              farthest point sampling            (reference: model/pointnet2_utils.py:63-84)
+//   ball_query       first-K in-radius indices           (reference: model/pointnet2_utils.py:87-107)
+//   three_nn_interp  3-NN inverse-distance interpolation (reference: model/pointnet2_utils.py:296-303)
+// All discrete selections reproduce the reference's arithmetic forms exactly: squared norms as
+// (x*x + y*y) + z*z with separate roundings, matmul-form distances as fma chains in k order
+// (what MKL's K=3 sgemm produces), `d > r*r` in fp32, stable first-index tie breaks.
+#include "common.hpp"
+#include "ev2hands_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float sqnorm3(float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// ---------------------------------------------------------------------------------------- prep
+__global__ __launch_bounds__(256) void prep_points_kernel(float* __restrict__ xyz_cm, int C, int N, int mhlnes,
+                                                          float4* __restrict__ pts4, float4* __restrict__ feat8) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float* base = xyz_cm + (size_t)b * C * N;
+    float f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) f[c] = (c < C) ? base[(size_t)c * N + n] : 0.f;
+    if (mhlnes) {
+        // TEHNet.py:176-177: channel 2 is overwritten IN PLACE by the mean of channels 3..C-1
+        float s = f[3];
+        for (int c = 4; c < C; ++c) s = __fadd_rn(s, f[c]);
+        s = s / (float)(C - 3);
+        f[2] = s;
+        base[(size_t)2 * N + n] = s;
+    }
+    pts4[(size_t)b * N + n] = make_float4(f[0], f[1], f[2], sqnorm3(f[0], f[1], f[2]));
+    feat8[((size_t)b * N + n) * 2 + 0] = make_float4(f[0], f[1], f[2], f[3]);
+    feat8[((size_t)b * N + n) * 2 + 1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// ---------------------------------------------------------------------------------------- FPS
+struct FpsJobs {
+    int njobs;
+    int S[3];
+    const int64_t* init[3];
+    int32_t* idx[3];
+    float4* ctr[3];
+};
+
+template <int PPT>
+__global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts4, int N, FpsJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* spts = reinterpret_cast<float4*>(smem_raw);
+    __shared__ unsigned long long skey[2][4];
+
+    const int b = blockIdx.x;
+    const int job = blockIdx.y;
+    const int S = jobs.S[job];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* src = pts4 + (size_t)b * N;
+
+    float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 256 + tid;
+        float4 v = (p < N) ? src[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < N) spts[p] = v;
+        px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+        md[j] = 1e10f;
+    }
+    __syncthreads();
+
+    int far = (int)jobs.init[job][b];
+    int32_t* oidx = jobs.idx[job] + (size_t)b * S;
+    float4* octr = jobs.ctr[job] + (size_t)b * S;
+
+    for (int i = 0; i < S; ++i) {
+        const float4 c = spts[far];
+        if (tid == 0) { oidx[i] = far; octr[i] = c; }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int p = j * 256 + tid;
+            const float dx = __fsub_rn(px[j], c.x), dy = __fsub_rn(py[j], c.y), dz = __fsub_rn(pz[j], c.z);
+            const float d = sqnorm3(dx, dy, dz);
+            if (d < md[j]) md[j] = d;
+            // key: larger distance first, then smaller index (torch.max returns the first maximum)
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(md[j]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
+            if (p < N && key > best) best = key;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) skey[i & 1][wave] = best;
+        __syncthreads();
+        unsigned long long k0 = skey[i & 1][0], k1 = skey[i & 1][1], k2 = skey[i & 1][2], k3 = skey[i & 1][3];
+        k0 = k0 > k1 ? k0 : k1;
+        k2 = k2 > k3 ? k2 : k3;
+        k0 = k0 > k2 ? k0 : k2;
+        far = (int)(0xffffffffu - (unsigned)(k0 & 0xffffffffull));
+    }
+}
+
+// ---------------------------------------------------------------------------------------- ball query
+struct BallArgs {
+    int nrad;
+    float r2[3];
+    int K[3];
+    int32_t* gidx[3];
+    int32_t* cnt;   // [B][S][nrad] (may be null)
+};
+
+constexpr int BALL_CTR_PER_WG = 32;
+
+__global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restrict__ pts4, const float4* __restrict__ ctr4,
+                                                         int N, int S, BallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* spts = reinterpret_cast<float4*>(smem_raw);
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4* src = pts4 + (size_t)b * N;
+    for (int p = tid; p < N; p += 256) spts[p] = src[p];
+    __syncthreads();
+
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int s_begin = blockIdx.x * BALL_CTR_PER_WG;
+    for (int s = s_begin + wave; s < s_begin + BALL_CTR_PER_WG && s < S; s += 4) {
+        const float4 c = ctr4[(size_t)b * S + s];
+        int cnt[3] = {0, 0, 0};
+        int first[3] = {0, 0, 0};
+        for (int base = 0; base < N; base += 64) {
+            const int p = base + lane;
+            const float4 q = spts[p < N ? p : N - 1];
+            // square_distance (pointnet2_utils.py:37-39): -2*(c.q) + |c|^2 + |q|^2, dot as an fma chain
+            const float dot = __fmaf_rn(c.z, q.z, __fmaf_rn(c.y, q.y, __fmul_rn(c.x, q.x)));
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), c.w), q.w);
+            bool done = true;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < a.nrad) {
+                    const bool in = (p < N) && !(d > a.r2[i]);
+                    const unsigned long long m = __ballot(in);
+                    if (cnt[i] == 0 && m != 0ull) first[i] = base + __ffsll((long long)m) - 1;
+                    const int pos = cnt[i] + __popcll(m & lt_mask);
+                    if (in && pos < a.K[i]) a.gidx[i][((size_t)b * S + s) * a.K[i] + pos] = p;
+                    cnt[i] += __popcll(m);
+                    done = done && (cnt[i] >= a.K[i]);
+                }
+            }
+            if (done) break;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (i < a.nrad) {
+                const int have = cnt[i] < a.K[i] ? cnt[i] : a.K[i];
+                for (int pos = have + lane; pos < a.K[i]; pos += 64)
+                    a.gidx[i][((size_t)b * S + s) * a.K[i] + pos] = first[i];
+                if (a.cnt && lane == 0) a.cnt[((size_t)b * S + s) * a.nrad + i] = have;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- 3-NN interpolation
+constexpr int NN_PTS_PER_WG = 256;
+
+__global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __restrict__ pts1, const float4* __restrict__ pts2,
+                                                              int N1, int N2, const float* __restrict__ feat2, int ldf2, int D,
+                                                              float* __restrict__ out, int ldo,
+                                                              int32_t* __restrict__ nn_idx, float* __restrict__ nn_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float4* s2 = reinterpret_cast<float4*>(smem_raw);                 // [N2]
+    int* sidx = reinterpret_cast<int*>(s2 + N2);                       // [256][3]
+    float* sw = reinterpret_cast<float*>(sidx + NN_PTS_PER_WG * 3);    // [256][3]
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < N2; p += 256) s2[p] = pts2[(size_t)b * N2 + p];
+    __syncthreads();
+
+    const int n = blockIdx.x * NN_PTS_PER_WG + tid;
+    if (n < N1) {
+        const float4 q = pts1[(size_t)b * N1 + n];
+        float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+        int i0 = 0, i1 = 0, i2 = 0;
+        for (int s = 0; s < N2; ++s) {
+            const float4 c = s2[s];
+            // src = xyz1 (q), dst = xyz2 (c): -2*dot + |q|^2 + |c|^2
+            const float dot = __fmaf_rn(q.z, c.z, __fmaf_rn(q.y, c.y, __fmul_rn(q.x, c.x)));
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), q.w), c.w);
+            if (d < d2) {               // strict: equal distances keep the earlier index (stable sort)
+                if (d < d1) {
+                    d2 = d1; i2 = i1;
+                    if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = s; }
+                    else        { d1 = d;  i1 = s; }
+                } else { d2 = d; i2 = s; }
+            }
+        }
+        const float r0 = __fdiv_rn(1.0f, __fadd_rn(d0, 1e-8f));
+        const float r1 = __fdiv_rn(1.0f, __fadd_rn(d1, 1e-8f));
+        const float r2 = __fdiv_rn(1.0f, __fadd_rn(d2, 1e-8f));
+        const float norm = __fadd_rn(__fadd_rn(r0, r1), r2);
+        const float w0 = __fdiv_rn(r0, norm), w1 = __fdiv_rn(r1, norm), w2 = __fdiv_rn(r2, norm);
+        sidx[tid * 3 + 0] = i0; sidx[tid * 3 + 1] = i1; sidx[tid * 3 + 2] = i2;
+        sw[tid * 3 + 0] = w0; sw[tid * 3 + 1] = w1; sw[tid * 3 + 2] = w2;
+        if (nn_idx) {
+            int32_t* o = nn_idx + ((size_t)b * N1 + n) * 3;
+            o[0] = i0; o[1] = i1; o[2] = i2;
+        }
+        if (nn_w) {
+            float* o = nn_w + ((size_t)b * N1 + n) * 3;
+            o[0] = w0; o[1] = w1; o[2] = w2;
+        }
+    }
+    __syncthreads();
+    if (!out) return;
+    // each wave interpolates 64 of the block's points, lanes across channels (float4)
+    const int D4 = D >> 2;
+    for (int t = wave * 64; t < wave * 64 + 64; ++t) {
+        const int nn = blockIdx.x * NN_PTS_PER_WG + t;
+        if (nn >= N1) break;
+        const int j0 = sidx[t * 3 + 0], j1 = sidx[t * 3 + 1], j2 = sidx[t * 3 + 2];
+        const float w0 = sw[t * 3 + 0], w1 = sw[t * 3 + 1], w2 = sw[t * 3 + 2];
+        const float4* f0 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j0) * ldf2);
+        const float4* f1 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j1) * ldf2);
+        const float4* f2 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j2) * ldf2);
+        float4* o = reinterpret_cast<float4*>(out + ((size_t)b * N1 + nn) * ldo);
+        for (int c = lane; c < D4; c += 64) {
+            const float4 a = f0[c], bq = f1[c], cq = f2[c];
+            float4 r;
+            // torch.sum(dim=2) of the three weighted rows: (a*w0 + b*w1) + c*w2, products rounded first
+            r.x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w0), __fmul_rn(bq.x, w1)), __fmul_rn(cq.x, w2));
+            r.y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w0), __fmul_rn(bq.y, w1)), __fmul_rn(cq.y, w2));
+            r.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(bq.z, w1)), __fmul_rn(cq.z, w2));
+            r.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(bq.w, w1)), __fmul_rn(cq.w, w2));
+            o[c] = r;
+        }
+    }
+}
+
+}  // namespace
+
+// ======================================================================================== C ABI
+extern "C" int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8,
+                                ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(xyz_cm && pts4 && feat8);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && C >= 4 && C <= 8);
+    dim3 grid(ceil_div(N, 256), B);
+    prep_points_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(xyz_cm, C, N, mhlnes, (float4*)pts4, (float4*)feat8);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init,
+                              int32_t* const* idx, float* const* ctr4, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(pts4 && S && init && idx && ctr4);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 8192 && njobs >= 1 && njobs <= 3);
+    FpsJobs jobs{};
+    jobs.njobs = njobs;
+    for (int j = 0; j < njobs; ++j) {
+        EV2H_CHECK_ARG(S[j] > 0 && init[j] && idx[j] && ctr4[j]);
+        jobs.S[j] = S[j];
+        jobs.init[j] = init[j];
+        jobs.idx[j] = idx[j];
+        jobs.ctr[j] = (float4*)ctr4[j];
+    }
+    dim3 grid(B, njobs);
+    const size_t lds = (size_t)N * sizeof(float4);
+    hipStream_t st = (hipStream_t)stream;
+    const float4* p = (const float4*)pts4;
+    if (N > 2048) {   // > 32 KiB of points: raise the dynamic-LDS limit once
+        static bool attr_set = false;
+        if (!attr_set) {
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+            attr_set = true;
+        }
+    }
+    if (N <= 256) fps_kernel<1><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 512) fps_kernel<2><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 1024) fps_kernel<4><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 2048) fps_kernel<8><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 4096) fps_kernel<16><<<grid, 256, lds, st>>>(p, N, jobs);
+    else fps_kernel<32><<<grid, 256, lds, st>>>(p, N, jobs);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_fps(const float* pts4, int B, int N, int S, const int64_t* init, int32_t* idx, float* ctr4,
+                        ev2h_stream_t stream) {
+    return ev2h_fps_multi(pts4, B, N, 1, &S, &init, &idx, &ctr4, stream);
+}
+
+extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const float* radius,
+                               const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(pts4 && ctr4 && radius && nsample && gidx);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 8192 && S > 0 && nrad >= 1 && nrad <= 3);
+    BallArgs a{};
+    a.nrad = nrad;
+    for (int i = 0; i < nrad; ++i) {
+        EV2H_CHECK_ARG(gidx[i] && nsample[i] > 0);
+        // `radius ** 2` is evaluated in python double and compared against fp32 distances
+        a.r2[i] = (float)((double)radius[i] * (double)radius[i]);
+        a.K[i] = nsample[i];
+        a.gidx[i] = gidx[i];
+    }
+    a.cnt = cnt;
+    dim3 grid(ceil_div(S, BALL_CTR_PER_WG), B);
+    if (N > 4096) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
+            attr_set = true;
+        }
+    }
+    ball_query_kernel<<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
+                                                                                       N, S, a);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, int B, int N1, int N2, const float* feat2,
+                                    int ldf2, int D, float* out, int ldo, int32_t* nn_idx, float* nn_w,
+                                    ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(pts1_4 && pts2_4);
+    EV2H_CHECK_ARG(B > 0 && N1 > 0 && N2 >= 3 && N2 <= 4096);
+    if (out) EV2H_CHECK_ARG(feat2 && D > 0 && (D % 4) == 0 && (ldf2 % 4) == 0 && (ldo % 4) == 0);
+    dim3 grid(ceil_div(N1, NN_PTS_PER_WG), B);
+    const size_t lds = (size_t)N2 * sizeof(float4) + NN_PTS_PER_WG * 3 * (sizeof(int) + sizeof(float));
+    three_nn_interp_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const float4*)pts1_4, (const float4*)pts2_4, N1, N2, feat2,
+                                                                    ldf2, D, out, ldo, nn_idx, nn_w);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}

@@ -1,0 +1,244 @@
+"""Drop-in host interface of the Ev2Hands per-frame inference path on MI355X.
+
+`TEHNetWrapper` and `TEHNet` keep the reference's surface
+(/root/reference/src/Ev2Hands/model/model.py:10-64, model/TEHNet.py:115-197): same constructor
+arguments, `forward(xyz, mano_hands)` positional signature, output dict, `state_dict()` keys
+(342 entries, strict-loadable), `module.` prefix stripping, `train()/eval()`, `.net/.hands/.rot`.
+The module tree below exists only to hold parameters under the reference's names; all arithmetic
+runs in libev2hands_hip.so through `ev2h_forward` (no torch ops, no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, synth
+from .mano import ManoHand, ManoOutput, create_mano_layers
+from .pack import PackedWeights
+
+
+# ------------------------------------------------------------------------------------ parameter containers
+class _MsgParams(nn.Module):
+    """names: conv_blocks.{i}.{j}, bn_blocks.{i}.{j} (pointnet2_utils.py:205-222)"""
+
+    def __init__(self, fan_in, mlps):
+        super().__init__()
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for mlp in mlps:
+            convs, bns, last = nn.ModuleList(), nn.ModuleList(), fan_in
+            for o in mlp:
+                convs.append(nn.Conv2d(last, o, 1))
+                bns.append(nn.BatchNorm2d(o))
+                last = o
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+
+class _StackParams(nn.Module):
+    """names: mlp_convs.{k}, mlp_bns.{k} (pointnet2_utils.py:161-174, 265-274)"""
+
+    def __init__(self, fan_in, mlp, dims):
+        super().__init__()
+        conv, bn = (nn.Conv2d, nn.BatchNorm2d) if dims == 2 else (nn.Conv1d, nn.BatchNorm1d)
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = fan_in
+        for o in mlp:
+            self.mlp_convs.append(conv(last, o, 1))
+            self.mlp_bns.append(bn(o))
+            last = o
+
+
+class _RegressorParams(nn.Module):
+    """names: sa1.*, sa2.*, mano_regressor.{0,2,4} (TEHNet.py:30-55)"""
+
+    def __init__(self, n_inp_features=4, n_pose_params=6, n_shape_params=10):
+        super().__init__()
+        self.sa1 = _MsgParams(n_inp_features + 3, synth.MANO_SA1_MLPS)
+        self.sa2 = _StackParams(512 + 3, synth.MANO_SA2_MLP, 2)
+        self.n_pose_params = n_pose_params
+        self.n_mano_params = n_pose_params + n_shape_params
+        self.mano_regressor = nn.Sequential(nn.Linear(512, 1024), nn.ReLU(), nn.BatchNorm1d(1024), nn.Dropout(0.3),
+                                            nn.Linear(1024, 3 + self.n_mano_params + 3))
+
+
+def _query_conv():
+    return nn.Sequential(nn.Conv1d(256, 256, 3, 1, 1), nn.ReLU(), nn.BatchNorm1d(256), nn.Dropout(0.1),
+                         nn.Conv1d(256, 256, 3, 1, 1), nn.BatchNorm1d(256))
+
+
+class TEHNet(nn.Module):
+    """TEHNet.py:115-197.  Input channel count follows env ERPC at construction (TEHNet.py:122)."""
+
+    def __init__(self, n_pose_params, num_classes=4):
+        super().__init__()
+        if num_classes != 4 or n_pose_params != synth.MANO_CMPS:
+            raise ValueError("the HIP path is built for num_classes=4, n_pose_params=6 (settings.MANO_CMPS)")
+        self.in_channels = 3 + 1 + int(os.getenv("ERPC", 0))
+        self.n_pose_params = n_pose_params
+        self.sa1 = _MsgParams(self.in_channels + 3, synth.SA1_MLPS)
+        self.sa2 = _MsgParams(320 + 3, synth.SA2_MLPS)
+        self.sa3 = _StackParams(512 + 3, synth.SA3_MLP, 2)
+        self.fp3 = _StackParams(1536, synth.FP3_MLP, 1)
+        self.fp2 = _StackParams(576, synth.FP2_MLP, 1)
+        self.fp1 = _StackParams(128, synth.FP1_MLP, 1)
+        self.classifier = nn.Sequential(nn.Conv1d(256, 256, 1), nn.ReLU(), nn.BatchNorm1d(256), nn.Dropout(0.3),
+                                        nn.Conv1d(256, num_classes, 1))
+        self.left_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
+        self.right_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
+        self.mhlnes = int(os.getenv("MHLNES", 0))
+        self.left_query_conv = _query_conv()
+        self.right_query_conv = _query_conv()
+        self._packed = None
+        self._packed_key = None
+        self._ws = None
+        self.fps_init = None          # optional override: list of four [B] int64 tensors for the next forward
+
+    # -- weight packing (re-done whenever parameters/buffers change or move) ---------------------
+    def _pack_key(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return (str(ts[0].device), tuple((t.data_ptr(), t._version) for t in ts))
+
+    def packed(self, device) -> PackedWeights:
+        key = (str(device), self._pack_key())
+        if self._packed is None or self._packed_key != key:
+            self._packed = PackedWeights(self.state_dict(), device, self.in_channels)
+            self._packed_key = key
+        return self._packed
+
+    def workspace(self, nbytes: int, device) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != torch.device(device):
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._ws
+
+    # -- forward ----------------------------------------------------------------------------------
+    def draw_fps_init(self, B: int, N: int):
+        """The reference seeds each farthest-point sampling with torch.randint on the global CPU
+        RNG (pointnet2_utils.py:75); same draws, same order: enc.sa1, enc.sa2, left.sa1, right.sa1."""
+        return [torch.randint(0, hi, (B,), dtype=torch.long) for hi in (N, synth.SA1_NPOINT, N, N)]
+
+    def forward(self, xyz, mano_hands):
+        if self.training:
+            raise NotImplementedError("ev2hands_amd implements the inference forward (net.eval()) only")
+        if xyz.dim() != 3 or xyz.shape[1] != self.in_channels:
+            raise RuntimeError(f"expected input [B, {self.in_channels}, N], got {tuple(xyz.shape)}")
+        if not xyz.is_cuda:
+            raise RuntimeError("ev2hands_amd runs on the GPU only (there is no CPU fallback); move the input to cuda")
+        if xyz.dtype != torch.float32:
+            raise RuntimeError("input must be float32")
+        device = xyz.device
+        B, Cin, N = xyz.shape
+        L = _lib.lib()
+        if self.mhlnes:
+            if not xyz.is_contiguous():
+                raise RuntimeError("MHLNES=1 writes channel 2 in place and needs a contiguous input")
+            x = xyz
+        else:
+            x = xyz.contiguous()
+        inits = self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N)
+        self.fps_init = None
+        init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
+
+        pw = self.packed(device)
+        native = all(isinstance(mano_hands[s], ManoHand) for s in ("left", "right"))
+        if not native:
+            raise TypeError("mano_hands must come from ev2hands_amd.create_mano_layers (ManoHand objects)")
+        cl, cr = mano_hands["left"].consts(), mano_hands["right"].consts()
+
+        f32 = dict(device=device, dtype=torch.float32)
+        logits = torch.empty(B, 4, N, **f32)
+        params = [torch.empty(B, synth.N_MANO_OUT, **f32) for _ in range(2)]
+        verts = [torch.empty(B, synth.MANO_NV, 3, **f32) for _ in range(2)]
+        joints = [torch.empty(B, 21, 3, **f32) for _ in range(2)]
+        out = _lib.Outputs()
+        out.class_logits = logits.data_ptr()
+        for h in range(2):
+            out.params[h] = params[h].data_ptr()
+            out.vertices[h] = verts[h].data_ptr()
+            out.joints[h] = joints[h].data_ptr()
+        nbytes = L.ev2h_workspace_bytes(B, N)
+        ws = self.workspace(nbytes, device)
+        with torch.cuda.device(device):
+            _lib.check(L.ev2h_forward(C.byref(pw.struct), C.byref(cl), C.byref(cr), x.data_ptr(), B, Cin, N, self.mhlnes,
+                                      init_dev.data_ptr(), C.byref(out), ws.data_ptr(), nbytes, _lib.stream_handle()),
+                       "ev2h_forward")
+        res = {"class_logits": logits}
+        npose = self.n_pose_params
+        for h, side in enumerate(("left", "right")):
+            p = params[h]
+            d = {"vertices": verts[h], "j3d": joints[h],
+                 "global_orient": p[:, :3], "hand_pose": p[:, 3:3 + npose], "betas": p[:, 3 + npose:-3],
+                 "transl": p[:, -3:]}
+            d["faces"] = np.tile(mano_hands[side].faces, (B, 1, 1))       # eval only (TEHNet.py:109-110)
+            res[side] = d
+        self._last_shape = (B, N)
+        return res
+
+    def debug_buffer(self, name: str, dtype=torch.float32) -> torch.Tensor:
+        """Copy of a named workspace buffer of the last forward (parity tests)."""
+        B, N = self._last_shape
+        L = _lib.lib()
+        cnt = C.c_size_t(0)
+        p = L.ev2h_workspace_buffer(self._ws.data_ptr(), B, N, name.encode(), C.byref(cnt))
+        if not p:
+            raise KeyError(name)
+        off = p - self._ws.data_ptr()
+        return self._ws[off:off + cnt.value * 4].view(dtype).clone()
+
+
+# ------------------------------------------------------------------------------------ wrapper
+def _rotation_x_180() -> torch.Tensor:
+    """trimesh.transformations.rotation_matrix(radians(180), [1,0,0]) (model.py:59), closed form."""
+    c, s = math.cos(math.pi), math.sin(math.pi)
+    return torch.tensor([[1.0, 0.0, 0.0, 0.0], [0.0, c, -s, 0.0], [0.0, s, c, 0.0], [0.0, 0.0, 0.0, 1.0]],
+                        dtype=torch.float64)
+
+
+class TEHNetWrapper:
+    """model.py:10-64.  `mano_assets` / `mano_path` say where the MANO constants come from (the
+    reference reads settings.MANO_PATH, which cannot be imported without pyrender)."""
+
+    def __init__(self, device, mano_path="../data/models", mano_assets=None):
+        self.net = TEHNet(n_pose_params=synth.MANO_CMPS).to(device)
+        self.net.eval()
+        self.training = False
+        self.hands = create_mano_layers(mano_path, device, synth.MANO_CMPS, assets=mano_assets)
+        self.rot = _rotation_x_180().to(device).float()
+
+    def state_dict(self):
+        return self.net.state_dict()
+
+    def load_state_dict(self, params, *args, **kwargs):
+        stripped = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in params.items()}
+        return self.net.load_state_dict(stripped, *args, **kwargs)
+
+    def parameters(self):
+        return self.net.parameters()
+
+    def train(self):
+        self.training = True
+        return self.net.train()
+
+    def eval(self):
+        self.training = False
+        return self.net.eval()
+
+    def P3dtoP2d(self, j3d, scale, translation):
+        B, N = j3d.shape[:2]
+        h = torch.cat([j3d, torch.ones(B, N, 1, device=j3d.device)], 2) @ self.rot.detach()
+        translation = translation.unsqueeze(1)
+        scale = scale.unsqueeze(1)
+        j2d = torch.zeros(B, N, 2, device=j3d.device)
+        j2d[:, :, 0] = translation[:, :, 0] + scale[:, :, 0] * h[:, :, 0]
+        j2d[:, :, 1] = translation[:, :, 1] + scale[:, :, 1] * h[:, :, 1]
+        return j2d
+
+    def __call__(self, inp):
+        return self.net(inp, self.hands)

@@ -1,0 +1,125 @@
+"""Operator-level host API over the C ABI, named after the reference functions they replace
+(/root/reference/src/Ev2Hands/model/pointnet2_utils.py).  Tensors in, tensors out, all on the GPU;
+every function calls straight into libev2hands_hip.so -- nothing here computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _st():
+    return _lib.stream_handle()
+
+
+def pack_points(xyz: torch.Tensor) -> torch.Tensor:
+    """[B,N,3] -> [B,N,4] with (x*x+y*y)+z*z in the 4th slot, via ev2h_prep_points."""
+    B, N, _ = xyz.shape
+    cm = torch.zeros(B, 4, N, device=xyz.device, dtype=torch.float32)
+    cm[:, :3] = xyz.permute(0, 2, 1)
+    pts4 = torch.empty(B, N, 4, device=xyz.device, dtype=torch.float32)
+    feat8 = torch.empty(B, N, 8, device=xyz.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ev2h_prep_points(cm.data_ptr(), B, 4, N, 0, pts4.data_ptr(), feat8.data_ptr(), _st()), "prep")
+    return pts4
+
+
+def farthest_point_sample(xyz: torch.Tensor, npoint: int, init: torch.Tensor | None = None) -> torch.Tensor:
+    """pointnet2_utils.py:63-84.  xyz [B,N,3] (cuda) -> int64 [B,npoint]."""
+    B, N, _ = xyz.shape
+    if init is None:
+        init = torch.randint(0, N, (B,), dtype=torch.long)
+    init = init.to(xyz.device, torch.long).contiguous()
+    pts4 = pack_points(xyz)
+    idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int32)
+    ctr = torch.empty(B, npoint, 4, device=xyz.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ev2h_fps(pts4.data_ptr(), B, N, npoint, init.data_ptr(), idx.data_ptr(), ctr.data_ptr(), _st()),
+               "ev2h_fps")
+    return idx.long()
+
+
+def query_ball_point(radius, nsample, xyz: torch.Tensor, new_xyz: torch.Tensor, return_counts: bool = False):
+    """pointnet2_utils.py:87-107.  radius / nsample may be scalars or equal-length lists (one pass)."""
+    radii = list(radius) if isinstance(radius, (list, tuple)) else [radius]
+    ks = list(nsample) if isinstance(nsample, (list, tuple)) else [nsample]
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    pts4, ctr4 = pack_points(xyz), pack_points(new_xyz)
+    outs = [torch.empty(B, S, k, device=xyz.device, dtype=torch.int32) for k in ks]
+    cnt = torch.empty(B, S, len(ks), device=xyz.device, dtype=torch.int32)
+    n = len(ks)
+    r_arr = (C.c_float * n)(*[float(r) for r in radii])
+    k_arr = (C.c_int * n)(*ks)
+    g_arr = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    _lib.check(_lib.lib().ev2h_ball_query(pts4.data_ptr(), ctr4.data_ptr(), B, N, S, n, r_arr, k_arr, g_arr, cnt.data_ptr(),
+                                          _st()), "ev2h_ball_query")
+    res = [o.long() for o in outs]
+    if not isinstance(radius, (list, tuple)):
+        res = res[0]
+    return (res, cnt) if return_counts else res
+
+
+def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Tensor):
+    """pointnet2_utils.py:296-303.  xyz1 [B,N,3], xyz2 [B,S,3], feat2 [B,S,D] -> (interp [B,N,D], idx, weight)."""
+    B, N, _ = xyz1.shape
+    S, D = xyz2.shape[1], feat2.shape[2]
+    p1, p2 = pack_points(xyz1), pack_points(xyz2)
+    f2 = feat2.contiguous()
+    out = torch.empty(B, N, D, device=xyz1.device, dtype=torch.float32)
+    idx = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int32)
+    w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    _lib.check(_lib.lib().ev2h_three_nn_interp(p1.data_ptr(), p2.data_ptr(), B, N, S, f2.data_ptr(), D, D, out.data_ptr(), D,
+                                               idx.data_ptr(), w.data_ptr(), _st()), "ev2h_three_nn_interp")
+    return out, idx.long(), w
+
+
+def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=None, post_shift=None, taps=1,
+          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None) -> torch.Tensor:
+    """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1]."""
+    M, ldx = X.shape
+    N, ldw = W.shape
+    K = (ldx if K is None else K)
+    rows_out = M // rowmax_rows if rowmax_rows else M
+    Y = torch.empty(rows_out, N, device=X.device, dtype=torch.float32)
+    d = _lib.GemmDesc()
+    d.X, d.ldx, d.W, d.ldw, d.Y, d.ldy = X.data_ptr(), ldx, W.data_ptr(), ldw, Y.data_ptr(), N
+    d.M, d.N, d.K = M, N, K
+    d.bias = _lib.ptr(bias)
+    d.bias_group_rows = bias_group_rows
+    d.ldbias = bias.shape[-1] if (bias is not None and bias_group_rows) else 0
+    d.relu = int(relu)
+    d.post_scale, d.post_shift = _lib.ptr(post_scale), _lib.ptr(post_shift)
+    d.taps, d.rows_per_seq, d.rowmax_rows = taps, rows_per_seq, rowmax_rows
+    L = _lib.lib()
+    _lib.check(L.ev2h_init(), "ev2h_init")
+    _lib.check(L.ev2h_gemm(C.byref(d), _st()), "ev2h_gemm")
+    return Y
+
+
+def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int) -> torch.Tensor:
+    """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3]."""
+    B, Npts, C1 = P1.shape
+    S, K = gidx.shape[1], gidx.shape[2]
+    C3 = W3.shape[0]
+    out = torch.empty(B, S, C3, device=P1.device, dtype=torch.float32)
+    d = _lib.SaDesc()
+    d.P1, d.ldp, d.pts4, d.ctr4, d.gidx = P1.data_ptr(), C1, pts4.data_ptr(), ctr4.data_ptr(), gidx.data_ptr()
+    d.W1x, d.W2, d.b2, d.W3, d.b3 = W1x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr()
+    d.out, d.ldo = out.data_ptr(), C3
+    d.B, d.Npts, d.S, d.K, d.C1, d.C2, d.C3 = B, Npts, S, K, C1, C2, C3
+    _lib.check(_lib.lib().ev2h_sa_mlp_max(C.byref(d), _st()), "ev2h_sa_mlp_max")
+    return out
+
+
+def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor):
+    """TEHNet.py:13-27 for both hands.  logits_pm [B,N,4], query_pm [2,B,N,256], value_pm [B,N,256]
+    -> (sim [B,2,4,256], hf8 [2,B,N,8])."""
+    B, N, _ = logits_pm.shape
+    sim = torch.empty(B, 2, 4, 256, device=logits_pm.device, dtype=torch.float32)
+    hf8 = torch.empty(2, B, N, 8, device=logits_pm.device, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.ev2h_attn_sim(logits_pm.data_ptr(), query_pm.data_ptr(), 256, B * N * 256, B, N, sim.data_ptr(), _st()), "sim")
+    _lib.check(L.ev2h_attn_context(sim.data_ptr(), value_pm.data_ptr(), 256, B, N, hf8.data_ptr(), _st()), "ctx")
+    return sim, hf8

@@ -1,0 +1,166 @@
+"""Checkpoint -> packed device weights for libev2hands_hip.so (host-side weight loading).
+
+Eval-mode BatchNorm is folded in float64 and rounded once to fp32:
+  * Conv -> BN -> ReLU blocks (set abstraction / feature propagation,
+    /root/reference/src/Ev2Hands/model/pointnet2_utils.py:198,256,314) fold into W, b;
+  * Conv/Linear -> ReLU -> BN blocks (classifier TEHNet.py:135-141, FC head :49-55, first query conv
+    :150-153) keep the BN as an explicit post-ReLU scale/shift -- folding it forward is not exact
+    for the zero-padded k=3 convolution;
+  * the second query conv (Conv -> BN, TEHNet.py:155-156) folds exactly.
+Layouts follow include/ev2hands_hip.h: layer-1 feature weights of all radius branches stacked
+(one table GEMM per module), W2 rows padded to 32, W3 columns padded to 8, group-all inputs
+re-ordered to [features | xyz | pad], k=3 conv weights tap-major.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+
+BN_EPS = 1e-5
+
+
+def _np(t) -> np.ndarray:
+    return t.detach().cpu().double().numpy()
+
+
+def _bn_affine(sd, p):
+    alpha = _np(sd[p + ".weight"]) / np.sqrt(_np(sd[p + ".running_var"]) + BN_EPS)
+    beta = _np(sd[p + ".bias"]) - _np(sd[p + ".running_mean"]) * alpha
+    return alpha, beta
+
+
+def _fold(sd, pc, pb):
+    """Conv -> BN: returns (W' [O, I...], b' [O]) in float64."""
+    W, b = _np(sd[pc + ".weight"]), _np(sd[pc + ".bias"])
+    alpha, beta = _bn_affine(sd, pb)
+    return W * alpha.reshape((-1,) + (1,) * (W.ndim - 1)), alpha * b + beta
+
+
+def _pad(a: np.ndarray, rows: int | None = None, cols: int | None = None) -> np.ndarray:
+    r = a.shape[0] if rows is None else rows
+    if a.ndim == 1:
+        out = np.zeros((r,), dtype=a.dtype)
+        out[:a.shape[0]] = a
+        return out
+    c = a.shape[1] if cols is None else cols
+    out = np.zeros((r, c), dtype=a.dtype)
+    out[:a.shape[0], :a.shape[1]] = a
+    return out
+
+
+def _up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class PackedWeights:
+    """Owns the device tensors and the ev2h_weights struct that points at them."""
+
+    def __init__(self, sd: dict, device, in_channels: int):
+        self.device = torch.device(device)
+        self.in_channels = in_channels
+        self._keep = []
+        self.tensors = {}
+        self.struct = _lib.Weights()
+        w = self.struct
+        self._sa_module(w.sa1, sd, "sa1", in_channels, 8, synth.SA1_NPOINT, synth.SA1_RADII, synth.SA1_NSAMPLE)
+        self._sa_module(w.sa2, sd, "sa2", 320, 320, synth.SA2_NPOINT, synth.SA2_RADII, synth.SA2_NSAMPLE)
+        for h, side in enumerate(("left", "right")):
+            p = f"{side}_mano_regressor"
+            self._sa_module(w.mano_sa1[h], sd, p + ".sa1", 4, 8, synth.MANO_SA1_NPOINT, synth.MANO_SA1_RADII,
+                            synth.MANO_SA1_NSAMPLE)
+            self._group_all(w.mano_sa2[h], sd, p + ".sa2", 2)
+            W, b = _np(sd[p + ".mano_regressor.0.weight"]), _np(sd[p + ".mano_regressor.0.bias"])
+            a, be = _bn_affine(sd, p + ".mano_regressor.2")
+            self._dense(w.head0[h], p + ".head0", W, b, a, be)
+            self._dense(w.head4[h], p + ".head4", _np(sd[p + ".mano_regressor.4.weight"]),
+                        _np(sd[p + ".mano_regressor.4.bias"]))
+        self._group_all(w.sa3, sd, "sa3", 3)
+        # fp3: 1536 = 512 skip (l2_points) + 1024 broadcast (l3_points), pointnet2_utils.py:293-294,307
+        W, b = _fold(sd, "fp3.mlp_convs.0", "fp3.mlp_bns.0")
+        W = W[:, :, 0]
+        self._dense(w.fp3_skip, "fp3.skip", W[:, :512], None)
+        self._dense(w.fp3_bcast, "fp3.bcast", W[:, 512:], b)
+        W, b = _fold(sd, "fp3.mlp_convs.1", "fp3.mlp_bns.1")
+        self._dense(w.fp3_1, "fp3.1", W[:, :, 0], b)
+        for k in range(2):
+            W, b = _fold(sd, f"fp2.mlp_convs.{k}", f"fp2.mlp_bns.{k}")
+            self._dense(w.fp2[k], f"fp2.{k}", W[:, :, 0], b)
+        for k in range(3):
+            W, b = _fold(sd, f"fp1.mlp_convs.{k}", f"fp1.mlp_bns.{k}")
+            self._dense(w.fp1[k], f"fp1.{k}", W[:, :, 0], b)
+        a, be = _bn_affine(sd, "classifier.2")
+        self._dense(w.cls0, "cls0", _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be)
+        self._dense(w.cls4, "cls4", _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
+        # query convs: tap-major [O][3*I]; both hands' first conv stacked along O
+        W0, b0, a0, be0 = [], [], [], []
+        for h, side in enumerate(("left", "right")):
+            p = f"{side}_query_conv"
+            W = _np(sd[p + ".0.weight"])                                  # [O, I, 3]
+            W0.append(np.ascontiguousarray(W.transpose(0, 2, 1)).reshape(W.shape[0], -1))
+            b0.append(_np(sd[p + ".0.bias"]))
+            a, be = _bn_affine(sd, p + ".2")
+            a0.append(a)
+            be0.append(be)
+            W4, b4 = _fold(sd, p + ".4", p + ".5")
+            W4 = np.ascontiguousarray(W4.transpose(0, 2, 1)).reshape(W4.shape[0], -1)
+            self._dense(w.qconv4[h], p + ".4", W4, b4, K=256)
+        self._dense(w.qconv0, "qconv0", np.concatenate(W0, 0), np.concatenate(b0), np.concatenate(a0),
+                    np.concatenate(be0), K=256)
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, name: str, a: np.ndarray) -> int:
+        t = torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(self.device)
+        self._keep.append(t)
+        self.tensors[name] = t
+        return t.data_ptr()
+
+    def _dense(self, d, name, W, b, post_scale=None, post_shift=None, K=None):
+        O, Kfull = W.shape
+        ldw = _up(Kfull, 4)
+        d.W = self._dev(name + ".W", _pad(W, O, ldw))
+        d.b = self._dev(name + ".b", b) if b is not None else None
+        d.post_scale = self._dev(name + ".ps", post_scale) if post_scale is not None else None
+        d.post_shift = self._dev(name + ".pt", post_shift) if post_shift is not None else None
+        d.O, d.K, d.ldw = O, (ldw if K is None else K), ldw
+
+    def _group_all(self, arr, sd, prefix, nlayers):
+        """sample_and_group_all concatenates [xyz(3), features(512)] (pointnet2_utils.py:155); our
+        buffers hold [features(512) | xyz(3) | 0 x 5] so that K = 520 is a multiple of 8."""
+        for k in range(nlayers):
+            W, b = _fold(sd, f"{prefix}.mlp_convs.{k}", f"{prefix}.mlp_bns.{k}")
+            W = W[:, :, 0, 0]
+            if k == 0:
+                assert W.shape[1] == 515
+                W = np.concatenate([W[:, 3:], W[:, :3], np.zeros((W.shape[0], 5))], 1)
+            self._dense(arr[k], f"{prefix}.{k}", W, b)
+
+    def _sa_module(self, m, sd, prefix, nfeat, kf, npoint, radii, nsamples):
+        W1f, b1 = [], []
+        m.kf, m.npoint, m.nbranch = kf, npoint, len(radii)
+        for i, (r, K) in enumerate(zip(radii, nsamples)):
+            Ws, bs = [], []
+            for j in range(3):
+                W, b = _fold(sd, f"{prefix}.conv_blocks.{i}.{j}", f"{prefix}.bn_blocks.{i}.{j}")
+                Ws.append(W[:, :, 0, 0])
+                bs.append(b)
+            C1, C2, C3 = (x.shape[0] for x in Ws)
+            assert Ws[0].shape[1] == nfeat + 3                 # [features..., dx, dy, dz] (pointnet2_utils.py:248)
+            W1f.append(_pad(Ws[0][:, :nfeat], C1, kf))
+            b1.append(bs[0])
+            br = m.br[i]
+            n = f"{prefix}.{i}"
+            br.W1x = self._dev(n + ".W1x", _pad(Ws[0][:, nfeat:], C1, 4))
+            br.W2 = self._dev(n + ".W2", _pad(Ws[1], _up(C2, 32), C1))
+            br.b2 = self._dev(n + ".b2", _pad(bs[1], _up(C2, 32)))
+            br.W3 = self._dev(n + ".W3", _pad(Ws[2], C3, _up(C2, 8)))
+            br.b3 = self._dev(n + ".b3", bs[2])
+            br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, K, float(r)
+        m.W1f = self._dev(prefix + ".W1f", np.concatenate(W1f, 0))
+        m.b1 = self._dev(prefix + ".b1", np.concatenate(b1, 0))
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 4 for t in self._keep)

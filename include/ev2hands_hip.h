@@ -1,0 +1,194 @@
+/* ev2hands_hip.h -- C ABI of libev2hands_hip.so: the MI355X (gfx950) implementation of the
+ * Ev2Hands per-frame inference hot path (TEHNet.forward + MANO layer, left and right hand).
+ *
+ * The reference has no native code and no FFI: its hot path is PyTorch eager ops called from
+ * /root/reference/src/Ev2Hands/model/model.py:61-64 (TEHNetWrapper.__call__ -> TEHNet.forward,
+ * model/TEHNet.py:168-197).  This header is therefore the boundary WE define underneath that
+ * Python interface (last-but-one row); each entry point names the reference
+ * lines whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers (fp32 / int32 / int64), explicit sizes, no torch types;
+ *  - the caller allocates and owns every input, output and workspace buffer;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *  - returns 0 on success, non-zero otherwise (EV2H_ERR_*); ev2h_last_error() gives the text;
+ *    nothing throws across the ABI;
+ *  - point-major layout inside the library: activations are [rows = points][channels] with the
+ *    channel axis contiguous; only the boundary tensors keep the reference's [B, C, N] layout.
+ */
+#ifndef EV2HANDS_HIP_H
+#define EV2HANDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EV2H_ABI_VERSION 1
+
+typedef void* ev2h_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int ev2h_abi_version(void);
+const char* ev2h_last_error(void);
+/* One-time per-process setup (raises dynamic-LDS limits of the big-tile kernels). Idempotent. */
+int ev2h_init(void);
+/* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs]. */
+void ev2h_struct_sizes(size_t out[6]);
+
+/* ---- point-set operators --------------------------------------------------------------------- */
+/* [B,C,N] channel-major input -> pts4 [B][N][4] = (x, y, z, (x*x+y*y)+z*z) and feat8 [B][N][8]
+ * (the C input channels, zero padded).  mhlnes != 0 reproduces TEHNet.py:176-177, including the
+ * in-place overwrite of input channel 2. */
+int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8, ev2h_stream_t stream);
+
+/* farthest_point_sample, model/pointnet2_utils.py:63-84.  init [B] int64 start indices (the
+ * reference draws them with torch.randint on the host, :75).  Writes idx [B][S] and the selected
+ * points ctr4 [B][S][4]. */
+int ev2h_fps(const float* pts4, int B, int N, int S, const int64_t* init, int32_t* idx, float* ctr4, ev2h_stream_t stream);
+/* Up to 3 independent samplings of the same clouds in one launch (host arrays of length njobs). */
+int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init,
+                   int32_t* const* idx, float* const* ctr4, ev2h_stream_t stream);
+
+/* query_ball_point, model/pointnet2_utils.py:87-107, for up to 3 radii of one centroid set in one
+ * pass.  radius / nsample / gidx are HOST arrays of length nrad; gidx[i] is a device buffer
+ * [B][S][nsample[i]] int32; cnt (optional, device) [B][S][nrad] receives min(#in-radius, nsample). */
+int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const float* radius,
+                    const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream);
+
+/* 3-NN inverse-distance interpolation, model/pointnet2_utils.py:296-303.  pts1 [B][N1][4] are the
+ * query points, pts2 [B][N2][4] the known points with features feat2 [B][N2][ldf2] (first D used).
+ * out [B][N1][ldo] (first D written; may be NULL), nn_idx / nn_w [B][N1][3] optional. */
+int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, int B, int N1, int N2, const float* feat2, int ldf2,
+                         int D, float* out, int ldo, int32_t* nn_idx, float* nn_w, ev2h_stream_t stream);
+
+/* ---- dense layers ------------------------------------------------------------------------------ */
+/* Y[m][n] = post( relu?( sum_{t<taps} sum_{k<K} X[m + t - (taps==3)][k] * W[n][t*K + k] + bias[n] ) )
+ * Replaces every Conv1d/Conv2d(1x1)/Linear (+ eval BatchNorm, folded by the caller or applied as
+ * post_scale/post_shift) of model/TEHNet.py:49-55,129-141,150-166 and model/pointnet2_utils.py:195-199,312-314. */
+typedef struct ev2h_gemm_desc {
+    const float* X; int ldx;     /* [M][ldx], K (x taps) used                                         */
+    const float* W; int ldw;     /* [N][ldw]                                                            */
+    float* Y; int ldy;           /* [M][ldy]  (or [M / rowmax_rows][ldy] when rowmax_rows != 0)         */
+    int M, N, K;                 /* K per tap, multiple of 4                                            */
+    const float* bias;           /* [N] or, with bias_group_rows, [M / bias_group_rows][ldbias]; NULL ok */
+    int bias_group_rows;         /* 0, or a multiple of 128                                             */
+    int ldbias;
+    int relu;
+    const float* post_scale;     /* optional y = y * post_scale[n] + post_shift[n] AFTER the ReLU       */
+    const float* post_shift;
+    int taps;                    /* 1, or 3 = Conv1d(k=3, padding=1) along rows, zero padded per sequence */
+    int rows_per_seq;            /* rows per window when taps == 3                                      */
+    int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
+} ev2h_gemm_desc;
+int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
+
+/* [B*N][4] point-major logits -> class_logits [B,4,N] (TEHNet.py:188,197). */
+int ev2h_transpose_logits(const float* logits_pm, int B, int N, float* logits_cm, ev2h_stream_t stream);
+
+/* ---- fused grouped set-abstraction MLP ----------------------------------------------------------- */
+/* out[b][s][c] = max_k relu(W3' relu(W2' relu(P1[b][gidx[b][s][k]] + W1x (xyz[idx] - ctr[b][s])) + b2') + b3')
+ * = model/pointnet2_utils.py:244-257 for one radius branch, with eval-BN folded into W/b and the
+ * feature part of layer 1 pre-computed per point (P1 = W1f' f + b1').
+ * Supported (C1,C2,C3): (32,32,64) (64,64,128) (64,96,128) (128,128,256) (128,196,256). */
+typedef struct ev2h_sa_desc {
+    const float* P1; int ldp;    /* [B][Npts][ldp], C1 columns used                                     */
+    const float* pts4;           /* [B][Npts][4]                                                        */
+    const float* ctr4;           /* [B][S][4]                                                           */
+    const int32_t* gidx;         /* [B][S][K]                                                           */
+    const float* W1x;            /* [C1][4]  folded weights of the 3 relative-xyz inputs (4th = 0)      */
+    const float* W2;             /* [roundup(C2,32)][C1], zero-padded rows                              */
+    const float* b2;             /* [roundup(C2,32)]                                                    */
+    const float* W3;             /* [C3][roundup(C2,8)], zero-padded columns                            */
+    const float* b3;             /* [C3]                                                                */
+    float* out; int ldo;         /* [B][S][ldo], C3 columns written                                     */
+    int B, Npts, S, K;           /* K multiple of 32                                                    */
+    int C1, C2, C3;
+} ev2h_sa_desc;
+int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
+
+/* ---- attention (model/TEHNet.py:13-27) ------------------------------------------------------------ */
+/* sim[b][h][c][d] = softmax_c( 256^-0.5 * sum_n logits[b][n][c] * query_h[b][n][d] ); query of hand h
+ * is query_pm + h*256 with row stride ldq.  logits_pm [B*N][4]; sim [B][2][4][256]. */
+int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int ldq, size_t query_hand_stride, int B, int N, float* sim,
+                  ev2h_stream_t stream);
+/* hf8[h][b*N + n][0..3] = sum_d sim[b][h][c][d] * value[b*N+n][d]; columns 4..7 are written as 0. */
+int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, ev2h_stream_t stream);
+
+/* ---- MANO layer (manopth ManoLayer.forward behind model/utils.py:25-31) ----------------------------- */
+typedef struct ev2h_mano_consts {
+    const float* hands_mean;     /* [45]                                                               */
+    const float* comps;          /* [ncomps][45]                                                       */
+    const float* blend_T;        /* [145][2336]: rows 0..9 shapedirs, 10..144 posedirs; column v*3+c   */
+    const float* v_template;     /* [2334]                                                             */
+    const float* J_template;     /* [48]      J_regressor @ v_template                                 */
+    const float* J_shape;        /* [10][48]  J_regressor @ shapedirs                                  */
+    const float* weights;        /* [778][16] skinning weights                                         */
+    int32_t tips[5];
+    int32_t ncomps;
+} ev2h_mano_consts;
+/* params [B][ldp] = global_orient(3) | hand_pose(ncomps) | betas(10) | transl(3)  (TEHNet.py:87-90).
+ * verts [B][778][3], joints [B][21][3] in metres (mm scaling and /1000 of utils.py:28-29 included). */
+int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, float* joints,
+              ev2h_stream_t stream);
+
+/* ---- whole path -------------------------------------------------------------------------------------- */
+typedef struct ev2h_sa_branch {
+    const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;
+    int C1, C2, C3, K;
+    float radius;
+} ev2h_sa_branch;
+
+typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
+    const float* W1f;             /* [sum C1][kf]  layer-1 feature weights of all branches, BN folded  */
+    const float* b1;              /* [sum C1]                                                          */
+    int kf;                       /* padded feature width of the input table                           */
+    int npoint;
+    int nbranch;
+    ev2h_sa_branch br[3];
+} ev2h_sa_module;
+
+typedef struct ev2h_dense {       /* one folded Conv/Linear: W [O][ldw], b [O], optional post affine    */
+    const float* W; const float* b; const float* post_scale; const float* post_shift;
+    int O, K, ldw;
+} ev2h_dense;
+
+typedef struct ev2h_weights {
+    ev2h_sa_module sa1, sa2, mano_sa1[2];       /* [0] = left, [1] = right                             */
+    ev2h_dense sa3[3];                           /* 520(=512 feat|xyz|pad) -> 256 -> 512 -> 1024       */
+    ev2h_dense fp3_skip, fp3_bcast, fp3_1;       /* 1536 split into 512 (skip) + 1024 (broadcast l3)   */
+    ev2h_dense fp2[2];
+    ev2h_dense fp1[3];
+    ev2h_dense cls0, cls4;
+    ev2h_dense qconv0;                           /* both hands, O = 512, 3 taps                        */
+    ev2h_dense qconv4[2];
+    ev2h_dense mano_sa2[2][2];
+    ev2h_dense head0[2], head4[2];
+} ev2h_weights;
+
+typedef struct ev2h_outputs {
+    float* class_logits;          /* [B,4,N]                                                           */
+    float* params[2];             /* [B][22]   left, right                                             */
+    float* vertices[2];           /* [B][778][3]                                                       */
+    float* joints[2];             /* [B][21][3]                                                        */
+} ev2h_outputs;
+
+size_t ev2h_workspace_bytes(int B, int N);
+/* TEHNet.forward, model/TEHNet.py:168-197, for B windows of N points with C channels.
+ * fps_init: device int64 [4][B] in the reference's RNG consumption order (enc.sa1, enc.sa2,
+ * left.sa1, right.sa1).  workspace: device buffer of at least ev2h_workspace_bytes(B, N). */
+int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
+                 float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
+                 void* workspace, size_t workspace_bytes, ev2h_stream_t stream);
+
+/* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in
+ * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown. */
+const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EV2HANDS_HIP_H */

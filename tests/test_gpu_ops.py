@@ -1,0 +1,216 @@
+"""GPU: every C-ABI operator against the oracle (or an fp64 restatement of the same formula) on
+seeded inputs.  Index outputs must be identical; float outputs within 1e-4 relative (||d||inf/||ref||inf),
+most are far tighter.  Runs through ev2hands_amd.ops -> ctypes -> libev2hands_hip.so."""
+import numpy as np
+import pytest
+import torch
+
+from ev2hands_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def rel(a, b):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def cloud_xyz(kind, B, N, seed):
+    return synth.synth_cloud(kind, B, 4, N, seed)[:, :3].permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("kind,N,S", [("U", 2048, 512), ("E", 2048, 128), ("U", 512, 128), ("E", 300, 64), ("U", 8192, 512)])
+def test_fps_indices_exact(kind, N, S):
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    B = 3
+    xyz = cloud_xyz(kind, B, N, 11)
+    init = synth.hash_randint("init", 0, N, (B,), 5)
+    init = torch.from_numpy(init)
+    ref = O.farthest_point_sample(xyz, S, init)
+    got = ops.farthest_point_sample(xyz.cuda(), S, init).cpu()
+    assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} FPS indices differ"
+
+
+def test_fps_degenerate_duplicates():
+    """fewer unique points than samples: argmax ties must resolve to the first index (torch.max)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    B, N, S = 2, 256, 64
+    base = cloud_xyz("U", B, 16, 3)
+    xyz = base.repeat(1, N // 16, 1).contiguous()
+    init = torch.tensor([5, 200])
+    ref = O.farthest_point_sample(xyz, S, init)
+    got = ops.farthest_point_sample(xyz.cuda(), S, init).cpu()
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("kind,N,S,radii,ks", [
+    ("U", 2048, 512, [0.1, 0.2, 0.4], [32, 64, 128]),
+    ("E", 2048, 128, [0.4, 0.8], [64, 128]),
+    ("E", 512, 128, [0.4, 0.8], [64, 128]),
+    ("U", 300, 40, [0.2], [32]),
+])
+def test_ball_query_exact(kind, N, S, radii, ks):
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    B = 2
+    xyz = cloud_xyz(kind, B, N, 21)
+    fps = O.farthest_point_sample(xyz, S, torch.zeros(B, dtype=torch.long))
+    ctr = O.gather_points(xyz, fps)
+    got, cnt = ops.query_ball_point(radii, ks, xyz.cuda(), ctr.cuda(), return_counts=True)
+    for i, (r, k) in enumerate(zip(radii, ks)):
+        ref = O.ball_query(r, k, xyz, ctr)
+        g = got[i].cpu()
+        assert torch.equal(g, ref), f"radius {r}: {(g != ref).sum().item()} of {ref.numel()} group indices differ"
+        d = O.pairwise_sqdist(ctr, xyz)
+        true_cnt = (~(d > r ** 2)).sum(-1).clamp(max=k)
+        assert torch.equal(cnt[:, :, i].cpu().long(), true_cnt)
+
+
+@pytest.mark.parametrize("kind,N1,N2,D", [("U", 2048, 512, 128), ("E", 2048, 512, 128), ("E", 512, 128, 256)])
+def test_three_nn_interp(kind, N1, N2, D):
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    B = 2
+    xyz1 = cloud_xyz(kind, B, N1, 31)
+    fps = O.farthest_point_sample(xyz1, N2, torch.zeros(B, dtype=torch.long))
+    xyz2 = O.gather_points(xyz1, fps)                       # subset => coincident points, d ~ 0 +- 5e-7
+    f2 = torch.from_numpy(synth.hash_normal("f2", (B, N2, D), 1)).float()
+    idx, w = O.three_nn_weights(xyz1, xyz2)
+    ref = (O.gather_points(f2, idx) * w.view(B, N1, 3, 1)).sum(dim=2)
+    out, gi, gw = ops.three_nn_interpolate(xyz1.cuda(), xyz2.cuda(), f2.cuda())
+    assert torch.equal(gi.cpu(), idx), f"{(gi.cpu() != idx).sum().item()} of {idx.numel()} 3-NN indices differ"
+    assert rel(gw, w) < 1e-5
+    assert rel(out, ref) < 1e-5
+
+
+GEMM_CASES = [
+    # M,   N,   K,  relu, post, taps, rowmax, group
+    (256, 128, 128, True, False, 1, 0, 0),
+    (300, 160, 8, False, False, 1, 0, 0),
+    (384, 256, 520, True, False, 1, 0, 0),
+    (1024, 4, 256, False, False, 1, 0, 0),
+    (5, 22, 1024, False, False, 1, 0, 0),
+    (7, 1024, 512, True, True, 1, 0, 0),
+    (512, 256, 256, True, True, 3, 0, 0),
+    (256, 512, 256, True, False, 1, 128, 0),
+    (384, 256, 512, True, False, 1, 0, 128),
+    (4096, 256, 576, True, False, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("M,N,K,relu,post,taps,rowmax,group", GEMM_CASES)
+def test_gemm(M, N, K, relu, post, taps, rowmax, group):
+    _need_gpu()
+    from ev2hands_amd import ops
+    X = torch.from_numpy(synth.hash_normal("X", (M, K), 2)).float()
+    W = torch.from_numpy(synth.hash_normal("W", (N, K * taps), 3) / np.sqrt(K * taps)).float()
+    ngrp = M // group if group else 1
+    b = torch.from_numpy(synth.hash_normal("b", (ngrp, N), 4)).float()
+    ps = torch.from_numpy(0.5 + synth.hash_uniform("ps", (N,), 5)).float() if post else None
+    pt = torch.from_numpy(synth.hash_normal("pt", (N,), 6)).float() if post else None
+    Xd, Wd = X.double(), W.double()
+    if taps == 3:
+        seq = 128
+        Xs = Xd.view(M // seq, seq, K)
+        z = torch.zeros(M // seq, 1, K, dtype=torch.float64)
+        Xcat = torch.cat([torch.cat([z, Xs[:, :-1]], 1), Xs, torch.cat([Xs[:, 1:], z], 1)], 2).view(M, 3 * K)
+        ref = Xcat @ Wd.t()
+    else:
+        seq = 0
+        ref = Xd @ Wd.t()
+    ref = ref + (b.double().repeat_interleave(group, 0) if group else b.double())
+    if relu:
+        ref = ref.clamp_min(0)
+    if post:
+        ref = ref * ps.double() + pt.double()
+    if rowmax:
+        ref = ref.view(M // rowmax, rowmax, N).max(1)[0]
+    got = ops.dense(X.cuda(), W.cuda(), b.cuda() if group else b[0].cuda(), relu, ps.cuda() if post else None,
+                    pt.cuda() if post else None, taps, seq, rowmax, group, K)
+    assert got.shape == ref.shape
+    assert rel(got, ref) < 2e-6
+
+
+SA_CASES = [(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128), (128, 128, 256, 64), (128, 196, 256, 128)]
+
+
+@pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
+def test_sa_mlp_max(C1, C2, C3, K):
+    _need_gpu()
+    from ev2hands_amd import ops
+    B, Npts, S = 2, 512, 37          # S deliberately not a multiple of the 8 groups per workgroup
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, C1 + C2) * sc).float()
+    P1 = g("P1", (B, Npts, C1))
+    xyz = cloud_xyz("U", B, Npts, 41)
+    ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), C3)).int()
+    W1x = g("W1x", (C1, 3), 0.5)
+    W2, b2 = g("W2", (C2, C1), C1 ** -0.5), g("b2", (C2,), 0.1)
+    W3, b3 = g("W3", (C3, C2), C2 ** -0.5), g("b3", (C3,), 0.1)
+    # fp64 restatement of pointnet2_utils.py:244-257 with layer 1 split as in the kernel
+    bi = torch.arange(B).view(B, 1, 1)
+    rows = P1.double()[bi, gidx.long()]                                        # [B,S,K,C1]
+    dxyz = (xyz[bi, gidx.long()] - ctr.view(B, S, 1, 3)).double()               # fp32 subtraction, like the reference
+    h1 = (rows + dxyz @ W1x.double().t()).clamp_min(0)
+    h2 = (h1 @ W2.double().t() + b2.double()).clamp_min(0)
+    h3 = (h2 @ W3.double().t() + b3.double()).clamp_min(0)
+    ref = h3.max(2)[0]
+    up = lambda x, m: (x + m - 1) // m * m
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = W1x
+    W2p = torch.zeros(up(C2, 32), C1); W2p[:C2] = W2
+    b2p = torch.zeros(up(C2, 32)); b2p[:C2] = b2
+    W3p = torch.zeros(C3, up(C2, 8)); W3p[:, :C2] = W3
+    pts4 = ops.pack_points(xyz.cuda())
+    ctr4 = ops.pack_points(ctr.cuda())
+    got = ops.sa_mlp_max(P1.cuda(), pts4, ctr4, gidx.cuda(), W1x4.cuda(), W2p.cuda(), b2p.cuda(), W3p.cuda(), b3.cuda(), C2)
+    assert rel(got, ref) < 2e-6
+
+
+def test_attention():
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    B, N = 2, 2048
+    g = lambda n, s: torch.from_numpy(synth.hash_normal(n, s, 9)).float()
+    key, value = g("k", (B, 4, N)), g("v", (B, 256, N))
+    q = [g("qL", (B, 256, N)) * 0.3, g("qR", (B, 256, N)) * 0.3]
+    ref = [O.attention(key, value, q[h]) for h in range(2)]
+    logits_pm = key.permute(0, 2, 1).contiguous().cuda()
+    query_pm = torch.stack([q[h].permute(0, 2, 1).contiguous() for h in range(2)]).cuda()
+    value_pm = value.permute(0, 2, 1).contiguous().cuda()
+    sim, hf8 = ops.attention(logits_pm, query_pm, value_pm)
+    for h in range(2):
+        got = hf8[h, :, :, :4].permute(0, 2, 1)
+        assert rel(got, ref[h]) < 1e-5
+        assert float(hf8[h, :, :, 4:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_mano_layer(side):
+    _need_gpu()
+    from ev2hands_amd.mano import ManoHand
+    from oracle import mano_oracle
+    a = synth.synth_mano_assets(side, 7)
+    B = 5
+    prm = torch.from_numpy(synth.hash_normal("prm", (B, 22), 8) * 0.5).float()
+    prm[:, 19:] *= 0.2
+    args = (prm[:, :3], prm[:, 3:9], prm[:, 9:19], prm[:, 19:])
+    ref = mano_oracle.ManoOracle(a)(*args)
+    ref64 = mano_oracle.ManoOracle(a, dtype=torch.float64)(*[x.double() for x in args])
+    hand = ManoHand(a, "cuda:0")
+    got = hand(*[x.cuda() for x in args])
+    assert rel(got.vertices, ref.vertices) < 1e-5 and rel(got.joints, ref.joints) < 1e-5
+    assert float((got.vertices.cpu().double() - ref64.vertices).abs().max()) < 1e-5     # metres
+    assert float((got.joints.cpu().double() - ref64.joints).abs().max()) < 1e-5
