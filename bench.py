@@ -1,0 +1,193 @@
+"""bench.py -- event-windows/s of the Ev2Hands per-frame inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W           (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path (TEHNet.forward + MANO, both hands) over one batch of synthetic
+event windows already resident in HBM: B=256 windows per GPU, N=2048 points, C=4, fp32 (the
+configuration BASELINE.json's metric is quoted on); with N>1 GPUs every rank runs its own shard of the
+global batch and the step ends with the RCCL all-gather of the predictions (weak scaling).
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the fused set-abstraction MLP of
+mano.sa1, r=0.8, K=128), timed with HIP events inside the timed region; `cpu_baseline` is the oracle
+(oracle/tehnet_oracle.py, PyTorch-CPU) on the host cores, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ev2hands_amd import _lib, dist as evdist, synth  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+# algorithmic work of the profiled kernel per window: layers 2+3 of mano.sa1 branch 1
+# (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
+PROFILED_TAG = "manoR.1"
+PROFILED_MAC_PER_WINDOW = 128 * 128 * (128 * 196 + 196 * 256)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="event windows per GPU per step")
+    ap.add_argument("--points", type=int, default=2048)
+    ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--cloud", default="E", choices=["U", "E"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+class HipEvents:
+    """hipEvent_t pairs created through libamdhip64 directly (torch.cuda.Event only sees torch's own records)."""
+
+    def __init__(self, n):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.n = n
+        self.start = (C.c_void_p * n)()
+        self.stop = (C.c_void_p * n)()
+        for arr in (self.start, self.stop):
+            for i in range(n):
+                ev = C.c_void_p()
+                assert self.hip.hipEventCreate(C.byref(ev)) == 0
+                arr[i] = ev
+
+    def elapsed_ms(self, used):
+        out = []
+        for i in range(min(used, self.n)):
+            ms = C.c_float()
+            rc = self.hip.hipEventElapsedTime(C.byref(ms), C.c_void_p(self.start[i]), C.c_void_p(self.stop[i]))
+            if rc == 0:
+                out.append(ms.value)
+        return out
+
+
+def cpu_baseline(sd, assets, B, C_, N, cloud, seconds):
+    """Oracle (port of the reference's CPU path) on the host cores, bounded sample."""
+    from oracle import mano_oracle, tehnet_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hands = mano_oracle.make_hands(assets["left"], assets["right"])
+    b = 8
+    xyz = synth.synth_cloud(cloud, b, C_, N, 99)
+    inits = synth.fps_inits(b, N, 99)
+    with torch.no_grad():
+        t0 = time.time()
+        tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits)      # warm-up, also sizes the sample
+        t1 = time.time() - t0
+        reps = max(1, min(8, int(seconds / max(t1, 1e-3))))
+        t0 = time.time()
+        for _ in range(reps):
+            tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits)
+        dt = time.time() - t0
+    return {"value": round(b * reps / dt, 3), "unit": "event-windows/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} forwards of B={b} N={N} C={C_} {cloud}-clouds, torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from ev2hands_amd.model import TEHNetWrapper
+
+    B, N, Cc = a.batch, a.points, a.channels
+    os.environ["ERPC"] = "1" if Cc == 5 else "0"
+    assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
+    sd = synth.synth_state_dict(Cc, 0)
+    net = TEHNetWrapper(dev, mano_assets=assets)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+
+    # this rank's shard of the global synthetic batch; FPS inits drawn for the global batch, then sliced
+    gB = B * world
+    lo, hi = evdist.shard_range(gB, rank, world)
+    full = synth.synth_cloud(a.cloud, B, Cc, N, seed=1000 + rank)          # per-rank seed == distinct windows
+    xyz = full.to(dev)
+    g_inits = synth.fps_inits(gB, N, 7)
+    inits = evdist.shard_fps_inits(g_inits, lo, hi)
+
+    L = _lib.lib()
+    nprof = max(a.steps, 1)
+    ev = HipEvents(nprof)
+
+    def step():
+        net.net.fps_init = inits
+        with torch.no_grad():
+            out = net(xyz)
+        if world > 1:
+            out = evdist.all_gather_outputs(out, N)
+        return out
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    L.ev2h_profile_set(PROFILED_TAG.encode(), ev.start, ev.stop, nprof)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    L.ev2h_profile_set(None, None, None, 0)
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        kms = ev.elapsed_ms(a.steps)
+        kavg = sum(kms) / max(len(kms), 1)
+        flops = 2.0 * PROFILED_MAC_PER_WINDOW * B
+        ach = flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
+        res = {
+            "metric": "event-windows/sec at B=256 N=2048",
+            "value": round(gB * a.steps / dt, 2),
+            "unit": "event-windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
+                                   f"random-init 342-key checkpoint, synthetic MANO-shaped assets",
+                       "global_batch": gB, "points": N, "channels": Cc,
+                       "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
+            "roofline": {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(kavg, 4), "flop_per_launch": flops},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, assets, B, Cc, N, a.cloud, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,8 +23,10 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return OUT
+    # -ffp-contract=off: hipcc would otherwise fuse a*b+c into fma and change the roundings the discrete
+    # selections (FPS argmax, radius test, 3-NN) are sensitive to; every intended fma is an explicit fmaf.
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I" + INCLUDE]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I" + CSRC, "-I" + INCLUDE]
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)

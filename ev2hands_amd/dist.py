@@ -1,0 +1,69 @@
+"""Multi-GPU: one process per GPU, contiguous batch shards, ONE all-gather of the packed predictions.
+
+Event windows are independent in eval mode (BatchNorm uses running statistics, no cross-sample op in
+/root/reference/src/Ev2Hands/model/TEHNet.py:168-197), so the path shards with no data-path collective;
+the only exchange is gathering the per-window outputs.  torch.distributed's
+"nccl" backend is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests.
+The reference's analogue is nn.DataParallel's scatter/gather (train.py:68), training only.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import synth
+
+PER_HAND = synth.N_MANO_OUT + synth.MANO_NV * 3 + 21 * 3      # 22 + 2334 + 63
+
+
+def packed_width(N: int) -> int:
+    return 4 * N + 2 * PER_HAND
+
+
+def shard_range(global_batch: int, rank: int, world: int):
+    """Contiguous slice [lo, hi) of the global batch owned by `rank` (remainder spread over the first ranks)."""
+    q, r = divmod(global_batch, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_fps_inits(inits, lo: int, hi: int):
+    """The four FPS start vectors are drawn once for the GLOBAL batch (reference RNG order) and sliced,
+    so that sharded == unsharded bit for bit."""
+    return [t[lo:hi].contiguous() for t in inits]
+
+
+def pack_outputs(out: dict) -> torch.Tensor:
+    """{'class_logits','left','right'} -> [B, 4N + 2*(22+2334+63)] float32 (one row per window)."""
+    B = out["class_logits"].shape[0]
+    parts = [out["class_logits"].reshape(B, -1)]
+    for side in ("left", "right"):
+        d = out[side]
+        parts += [d["global_orient"], d["hand_pose"], d["betas"], d["transl"], d["vertices"].reshape(B, -1),
+                  d["j3d"].reshape(B, -1)]
+    return torch.cat(parts, 1).contiguous()
+
+
+def unpack_outputs(buf: torch.Tensor, N: int, n_pose: int = synth.MANO_CMPS) -> dict:
+    B = buf.shape[0]
+    out = {"class_logits": buf[:, :4 * N].reshape(B, 4, N)}
+    o = 4 * N
+    for side in ("left", "right"):
+        d = {}
+        for k, w in (("global_orient", 3), ("hand_pose", n_pose), ("betas", 10), ("transl", 3),
+                     ("vertices", synth.MANO_NV * 3), ("j3d", 63)):
+            d[k] = buf[:, o:o + w]
+            o += w
+        d["vertices"] = d["vertices"].reshape(B, synth.MANO_NV, 3)
+        d["j3d"] = d["j3d"].reshape(B, 21, 3)
+        out[side] = d
+    return out
+
+
+def all_gather_outputs(out: dict, N: int, group=None) -> dict:
+    """All ranks end up with the predictions of the whole global batch (equal shard sizes)."""
+    local = pack_outputs(out)
+    world = dist.get_world_size(group)
+    full = torch.empty(world * local.shape[0], local.shape[1], device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(full, local, group=group)
+    return unpack_outputs(full, N)

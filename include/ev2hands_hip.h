@@ -184,6 +184,11 @@ int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const
                  float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
                  void* workspace, size_t workspace_bytes, ev2h_stream_t stream);
 
+/* Measurement hook (bench.py): record caller-owned hipEvent_t pairs around ONE launch site of
+ * ev2h_forward, on the forward's stream.  tag = "<module>.<branch>" with module in {sa1, sa2, manoL,
+ * manoR} (the fused set-abstraction kernels).  Call i uses pair i % n.  tag == NULL disables. */
+int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, int n);
+
 /* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in
  * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown. */
 const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);

@@ -224,6 +224,8 @@ def tehnet_forward(sd, xyz_in, mano_hands, fps_init=None, n_pose=6, training=Fal
     l1_xyz, l1 = sa_msg(sd, "sa1", xyz0, feat0, S.SA1_NPOINT, S.SA1_RADII, S.SA1_NSAMPLE, fi[0], trace)
     l2_xyz, l2 = sa_msg(sd, "sa2", l1_xyz, l1, S.SA2_NPOINT, S.SA2_RADII, S.SA2_NSAMPLE, fi[1], trace)
     l3_xyz, l3 = sa_group_all(sd, "sa3", l2_xyz, l2)
+    if trace is not None:
+        trace.update({"sa1_points": l1, "sa2_points": l2})
     l2 = feature_propagation(sd, "fp3", l2_xyz, l3_xyz, l2, l3, trace)
     l1 = feature_propagation(sd, "fp2", l1_xyz, l2_xyz, l1, l2, trace)
     l0 = feature_propagation(sd, "fp1", xyz0, l1_xyz, None, l1, trace)

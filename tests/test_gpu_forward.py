@@ -61,9 +61,19 @@ def check_against(out, net, ref, trace, B, N):
         "sa2.group0": ("gidx2_0", (B, 128, 64)), "sa2.group1": ("gidx2_1", (B, 128, 128)),
         "left_mano_regressor.sa1.group0": ("gidxm0L", (B, 128, 64)), "left_mano_regressor.sa1.group1": ("gidxm1L", (B, 128, 128)),
         "right_mano_regressor.sa1.group0": ("gidxm0R", (B, 128, 64)), "right_mano_regressor.sa1.group1": ("gidxm1R", (B, 128, 128)),
-        "fp2.nn_idx": ("nn2_idx", (B, 512, 3)), "fp1.nn_idx": ("nn1_idx", (B, N, 3)),
     }
     bad = {}
+    # 3-NN: compare the selected neighbours by coordinates -- with fewer than 512 unique points the
+    # sampled set holds duplicates, equal distances tie, and torch.sort's order among ties is unspecified
+    l1_xyz = trace["l1_xyz"].permute(0, 2, 1)
+    l2_xyz = trace["l2_xyz"].permute(0, 2, 1)
+    bi = torch.arange(B).view(B, 1, 1)
+    for tname, bname, shape, pts in (("fp2.nn_idx", "nn2_idx", (B, 512, 3), l2_xyz), ("fp1.nn_idx", "nn1_idx", (B, N, 3), l1_xyz)):
+        got = net.net.debug_buffer(bname, torch.int32).view(shape).cpu().long()
+        want = torch.as_tensor(np.asarray(trace[tname])).long()
+        n = int((pts[bi, got] != pts[bi, want]).any(-1).sum())
+        if n:
+            bad[tname] = n
     for tname, (bname, shape) in sel.items():
         got = net.net.debug_buffer(bname, torch.int32).view(shape).cpu().long()
         want = torch.as_tensor(np.asarray(trace[tname])).long()
@@ -72,7 +82,7 @@ def check_against(out, net, ref, trace, B, N):
             bad[tname] = n
     # intermediate features (diagnostics + tolerance)
     feats = {
-        "l1_points": ("l1cat", (B, 512, 576), slice(0, 320)),
+        "sa1_points": ("l1cat", (B, 512, 576), slice(0, 320)),
         "l0_points": ("l0", (B, N, 256), slice(0, 256)),
     }
     for tname, (bname, shape, cols) in feats.items():
@@ -123,10 +133,16 @@ def test_forward_matches_reference_fixture(path):
         assert rel(prm, g[side + ".params"]) < TOL
         assert rel(out[side]["vertices"], g[f"unpinned.{side}.vertices"]) < TOL
         assert rel(out[side]["j3d"], g[f"unpinned.{side}.j3d"]) < TOL
-    for name, buf in (("sa1.fps", "fps1"), ("sa2.fps", "fps2"), ("sa1.group2", "gidx1_2"), ("sa2.group1", "gidx2_1"),
-                      ("fp1.nn_idx", "nn1_idx")):
+    for name, buf in (("sa1.fps", "fps1"), ("sa2.fps", "fps2"), ("sa1.group2", "gidx1_2"), ("sa2.group1", "gidx2_1")):
         got = net.net.debug_buffer(buf, torch.int32).cpu().numpy().reshape(g[name].shape)
         assert np.array_equal(got, g[name].astype(np.int32)), name
+    # 3-NN by neighbour coordinates (ties among duplicated sample points have no defined order in torch.sort)
+    l1_xyz = torch.from_numpy(g["sa1.new_xyz"]).permute(0, 2, 1)
+    bi = torch.arange(B).view(B, 1, 1)
+    got = net.net.debug_buffer("nn1_idx", torch.int32).view(B, N, 3).cpu().long()
+    want = torch.from_numpy(g["fp1.nn_idx"].astype(np.int64))
+    assert torch.equal(l1_xyz[bi, got], l1_xyz[bi, want])
+    assert rel(net.net.debug_buffer("nn1_w").view(B, N, 3), g["fp1.nn_w"]) < 1e-5
     hf = net.net.debug_buffer("hf8").view(2, B, N, 8)
     for h, side in enumerate(("left", "right")):
         assert rel(hf[h, :, :, :4].permute(0, 2, 1), g[side + ".hand_features"]) < TOL
