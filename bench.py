@@ -72,20 +72,22 @@ class HipEvents:
         return out
 
 
-def cpu_baseline(sd, assets, B, C_, N, cloud, seconds):
-    """Oracle (port of the reference's CPU path) on the host cores, bounded sample."""
+def cpu_baseline(sd, assets, C_, N, cloud, seconds):
+    """Oracle (port of the reference's CPU path) on the host cores, bounded sample.  PyTorch-CPU scales
+    badly past a few dozen threads on these small ops (256 threads measured 100x slower than 16), so
+    the baseline uses at most 16 threads and says so in `cores`."""
     from oracle import mano_oracle, tehnet_oracle
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     hands = mano_oracle.make_hands(assets["left"], assets["right"])
-    b = 8
+    b = 4
     xyz = synth.synth_cloud(cloud, b, C_, N, 99)
     inits = synth.fps_inits(b, N, 99)
     with torch.no_grad():
         t0 = time.time()
-        tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits)      # warm-up, also sizes the sample
-        t1 = time.time() - t0
-        reps = max(1, min(8, int(seconds / max(t1, 1e-3))))
+        tehnet_oracle.tehnet_forward(sd, xyz[:1].clone(), hands, fps_init=[t[:1] for t in inits])   # warm-up + sizing
+        t1 = (time.time() - t0) * b
+        reps = max(1, min(16, int(seconds / max(t1, 1e-3))))
         t0 = time.time()
         for _ in range(reps):
             tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits)
@@ -182,7 +184,7 @@ def main():
                          "kernel_ms": round(kavg, 4), "flop_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(sd, assets, B, Cc, N, a.cloud, a.cpu_seconds)
+            res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
