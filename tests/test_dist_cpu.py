@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: batch sharding + the one all-gather of packed predictions."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ev2hands_amd import dist as evdist, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_outputs(lo, hi, N):
+    """Deterministic per-window 'predictions' standing in for the GPU forward (value = f(window index))."""
+    B = hi - lo
+    w = torch.arange(lo, hi, dtype=torch.float32).view(B, 1)
+    out = {"class_logits": (w.view(B, 1, 1) + torch.arange(4 * N, dtype=torch.float32).view(1, 4, N) * 1e-3)}
+    for s, side in enumerate(("left", "right")):
+        out[side] = {"global_orient": w + torch.arange(3) + s, "hand_pose": w + torch.arange(6) * 2 + s,
+                     "betas": w + torch.arange(10) * 3 + s, "transl": w + torch.arange(3) * 4 + s,
+                     "vertices": (w.view(B, 1, 1) + torch.arange(778 * 3, dtype=torch.float32).view(1, 778, 3) * 1e-2 + s),
+                     "j3d": (w.view(B, 1, 1) + torch.arange(63, dtype=torch.float32).view(1, 21, 3) + s)}
+    return out
+
+
+def _worker(rank, world, port, gB, N, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = evdist.shard_range(gB, rank, world)
+    inits = synth.fps_inits(gB, N, 5)
+    mine = evdist.shard_fps_inits(inits, lo, hi)
+    assert all(m.shape[0] == hi - lo for m in mine) and torch.equal(mine[2], inits[2][lo:hi])
+    full = evdist.all_gather_outputs(_fake_outputs(lo, hi, N), N)
+    want = _fake_outputs(0, gB, N)
+    ok = torch.equal(full["class_logits"], want["class_logits"])
+    for side in ("left", "right"):
+        for k in want[side]:
+            ok = ok and torch.equal(full[side][k], want[side][k]) and full[side][k].shape == want[side][k].shape
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_all_gather_of_sharded_predictions_world2():
+    world, gB, N = 2, 6, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gB, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_ranges_cover_batch():
+    for gB in (1, 7, 256, 2048):
+        for world in (1, 2, 4, 8):
+            r = [evdist.shard_range(gB, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == gB
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+
+
+def test_pack_unpack_roundtrip():
+    N = 128
+    out = _fake_outputs(3, 8, N)
+    back = evdist.unpack_outputs(evdist.pack_outputs(out), N)
+    assert torch.equal(back["class_logits"], out["class_logits"])
+    assert torch.equal(back["right"]["vertices"], out["right"]["vertices"])
+    assert evdist.pack_outputs(out).shape[1] == evdist.packed_width(N)
