@@ -72,6 +72,20 @@ class HipEvents:
         return out
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the profiled kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_hbm_traffic_*.json: (2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_*.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"]["sa_mlp_max_kernel<128, 196, 256>"]
+        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch_corrected"], "source": os.path.basename(files[-1])}
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, assets, C_, N, cloud, seconds):
     """Oracle (port of the reference's CPU path) on the host cores, bounded sample.  PyTorch-CPU scales
     badly past a few dozen threads on these small ops (256 threads measured 100x slower than 16), so
@@ -180,7 +194,7 @@ def main():
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
                          "kernel_ms": round(kavg, 4), "flop_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -57,6 +57,9 @@ struct SaCfg {
     static constexpr int LDS_FLOATS = 2 * TILE + C1 * 4 + T2 * 32;
     static constexpr int REM = C2 % 32;
     static constexpr int NQ_LAST = REM ? (REM + 7) / 8 : 4;   // live 8-channel blocks of the last layer-2 tile
+    // prefetch the next 32-channel chunk of gathered P1 rows one chunk ahead, except where the 7x16
+    // accumulator registers leave no room (the second wave on the SIMD hides that latency instead)
+    static constexpr bool PREFETCH_P1 = (T2 < 7);
 };
 
 template <int C1, int C2, int C3>
@@ -152,6 +155,10 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_mlp_max_kernel(SaP p) {
         for (int c = 0; c < NC1; ++c) {
             float* cur = buf ? wt1 : wt0;
             float* nxt = buf ? wt0 : wt1;
+            if (!Cfg::PREFETCH_P1 && c > 0) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = prow[c * 8 + j4];
+            }
             if (c + 1 < NC1) load_w2(c + 1); else load_w3(0);
             // layer-1 finish: relu(P1 + W1x . (xyz[idx] - ctr)), exact relative coordinates as in the reference
             float h1[16];
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_mlp_max_kernel(SaP p) {
                     h1[j4 * 4 + e] = fmaxf(t, 0.f);
                 }
             }
-            if (c + 1 < NC1) {
+            if (Cfg::PREFETCH_P1 && c + 1 < NC1) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = prow[(c + 1) * 8 + j4];
             }

@@ -96,7 +96,8 @@ def check_against(out, net, ref, trace, B, N):
     assert same
 
 
-@pytest.mark.parametrize("kind,C,N,B,seed", [("U", 4, 2048, 2, 0), ("E", 5, 2048, 2, 1), ("E", 4, 2048, 3, 4), ("U", 5, 256, 2, 2)])
+@pytest.mark.parametrize("kind,C,N,B,seed", [("U", 4, 2048, 2, 0), ("E", 5, 2048, 2, 1), ("E", 4, 2048, 3, 4), ("U", 5, 256, 2, 2),
+                                              ("E", 4, 8192, 1, 5), ("U", 5, 1000, 2, 6)])
 def test_forward_matches_oracle(kind, C, N, B, seed):
     _need_gpu()
     net, sd, assets = make_net(C, seed)

@@ -1,0 +1,63 @@
+"""Micro-benchmarks of the two MFMA kernels at the bench shapes (B=256, N=2048): python tools/kbench.py [sa|gemm|all]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ev2hands_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def bench_sa(B=256):
+    up = lambda x, m: (x + m - 1) // m * m
+    for (C1, C2, C3, K, S, Npts, tag) in [(32, 32, 64, 32, 512, 2048, "enc.sa1.0"), (64, 64, 128, 64, 512, 2048, "enc.sa1.1"),
+                                          (64, 96, 128, 128, 512, 2048, "enc.sa1.2"), (128, 128, 256, 64, 128, 2048, "mano.0"),
+                                          (128, 196, 256, 128, 128, 2048, "mano.1"), (128, 196, 256, 128, 128, 512, "enc.sa2.1")]:
+        d = "cuda"
+        P1 = torch.randn(B, Npts, C1, device=d)
+        pts4 = torch.randn(B, Npts, 4, device=d)
+        ctr4 = torch.randn(B, S, 4, device=d)
+        gidx = torch.randint(0, Npts, (B, S, K), device=d, dtype=torch.int32)
+        W1x = torch.randn(C1, 4, device=d)
+        W2 = torch.randn(up(C2, 32), C1, device=d) * C1 ** -0.5
+        b2 = torch.randn(up(C2, 32), device=d)
+        W3 = torch.randn(C3, up(C2, 8), device=d) * C2 ** -0.5
+        b3 = torch.randn(C3, device=d)
+        ms = timeit(lambda: ops.sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2))
+        flop = 2.0 * B * S * K * (C1 * C2 + C2 * C3)
+        print(f"sa<{C1},{C2},{C3}> K={K} S={S} {tag:10s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
+
+
+def bench_gemm(B=256, N=2048):
+    R = B * N
+    for (M, Nn, K, taps, tag) in [(R, 512, 256, 3, "qconv0"), (R, 256, 256, 3, "qconv4"), (R, 256, 128, 1, "fp1.2"), (R, 128, 128, 1, "fp1.0"),
+                                  (R, 256, 256, 1, "cls0"), (R, 4, 256, 1, "cls4"), (R, 160, 8, 1, "P1a"), (R, 256, 8, 1, "P1m"),
+                                  (B * 512, 256, 576, 1, "fp2.0"), (B * 512, 256, 320, 1, "P1b"), (B * 128, 256, 520, 1, "sa3.0"),
+                                  (B * 128, 1024, 512, 1, "sa3.2")]:
+        X = torch.randn(M, K, device="cuda")
+        W = torch.randn(Nn, K * taps, device="cuda") * (K * taps) ** -0.5
+        b = torch.randn(Nn, device="cuda")
+        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K))
+        flop = 2.0 * M * Nn * K * taps
+        print(f"gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("sa", "all"):
+        bench_sa()
+    if what in ("gemm", "all"):
+        bench_gemm()
