@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--cloud", default="E", choices=["U", "E"])
+    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the MFMA contractions (f32 exact | bf16x3 fp32-class split | bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -126,6 +128,7 @@ def main():
 
     B, N, Cc = a.batch, a.points, a.channels
     os.environ["ERPC"] = "1" if Cc == 5 else "0"
+    os.environ["EV2H_PRECISION"] = a.precision
     assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
     sd = synth.synth_state_dict(Cc, 0)
     net = TEHNetWrapper(dev, mano_assets=assets)

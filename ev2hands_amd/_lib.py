@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
                 ("M", ci), ("N", ci), ("K", ci),
                 ("bias", vp), ("bias_group_rows", ci), ("ldbias", ci), ("relu", ci),
                 ("post_scale", vp), ("post_shift", vp),
-                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci)]
+                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci)]
 
 
 class SaDesc(C.Structure):
@@ -28,12 +28,12 @@ class SaDesc(C.Structure):
                 ("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("out", vp), ("ldo", ci),
                 ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
-                ("C1", ci), ("C2", ci), ("C3", ci)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp)]
 
 
 class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float), ("W2s", vp), ("W3s", vp)]
 
 
 class SaModule(C.Structure):
@@ -52,7 +52,9 @@ class Weights(C.Structure):
                 ("cls0", Dense), ("cls4", Dense),
                 ("qconv0", Dense), ("qconv4", Dense * 2),
                 ("mano_sa2", (Dense * 2) * 2),
-                ("head0", Dense * 2), ("head4", Dense * 2)]
+                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci)]
+
+PREC = {"f32": 0, "bf16": 1, "bf16x3": 3}
 
 
 class ManoConsts(C.Structure):

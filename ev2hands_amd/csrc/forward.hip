@@ -196,6 +196,8 @@ struct Ws {
         if (rc__) return rc__;    \
     } while (0)
 
+static thread_local int g_precision = EV2H_PREC_F32;   // set by ev2h_forward for the helpers below (single in-flight forward per thread)
+
 static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st,
                  const float* group_bias = nullptr, int group_rows = 0, int ldbias = 0, int taps = 1, int rows_per_seq = 0,
                  int rowmax_rows = 0) {
@@ -206,17 +208,19 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     d.bias_group_rows = group_rows; d.ldbias = ldbias;
     d.relu = relu; d.post_scale = w.post_scale; d.post_shift = w.post_shift;
     d.taps = taps; d.rows_per_seq = rows_per_seq; d.rowmax_rows = rowmax_rows;
+    d.precision = g_precision;
     return ev2h_gemm(&d, st);
 }
 
 // one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius
-static int sa_module(const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
+static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
                      int32_t* const* gidx, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     ev2h_gemm_desc g{};
     g.X = feat; g.ldx = ldf; g.W = m.W1f; g.ldw = m.kf; g.Y = P1; g.ldy = c1sum;
     g.M = B * Npts; g.N = c1sum; g.K = m.kf; g.bias = m.b1; g.taps = 1;
+    g.precision = precision;
     RUN(ev2h_gemm(&g, st));
     int coff1 = 0, coff3 = 0;
     for (int i = 0; i < m.nbranch; ++i) {
@@ -226,6 +230,7 @@ static int sa_module(const char* tag, const ev2h_sa_module& m, const float* feat
         d.W1x = br.W1x; d.W2 = br.W2; d.b2 = br.b2; d.W3 = br.W3; d.b3 = br.b3;
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
+        d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s;
         char t[40];
         snprintf(t, sizeof(t), "%s.%d", tag, i);
         prof_begin(t, st);
@@ -266,6 +271,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
     EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
     RUN(ev2h_init());
+    g_precision = w->precision;
     Ws ws;
     ws.base = static_cast<char*>(workspace);
     build_layout(ws.L, B, N);
@@ -292,7 +298,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
-        RUN(sa_module("sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
+        RUN(sa_module(w->precision, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
     {
@@ -302,7 +308,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         int32_t* gi[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
         for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi, ws.i("cnt2"), st));
-        RUN(sa_module("sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
+        RUN(sa_module(w->precision, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
                                                                                    ws.f("l2buf"), 520, 512);
         EV2H_CHECK_LAUNCH();
@@ -345,7 +351,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
         for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f(nm[2]), B, N, 128, 2, rad, ns, gi, ws.i(nm[5]), st));
-        RUN(sa_module(h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, st));
+        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, st));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
                                                                                    ws.f(nm[6]), 520, 512);
         EV2H_CHECK_LAUNCH();

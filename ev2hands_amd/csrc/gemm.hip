@@ -196,6 +196,8 @@ int ev2h_gemm_init() {
     return EV2H_OK;
 }
 
+int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream);
+
 extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d && d->X && d->W && d->Y);
     EV2H_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0);
@@ -212,6 +214,7 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->post_scale == nullptr) == (d->post_shift == nullptr));
     p.rowmax_rows = d->rowmax_rows;
     if (d->rowmax_rows) EV2H_CHECK_ARG(d->rowmax_rows == BM && d->M % BM == 0);
+    if (d->precision != EV2H_PREC_F32) return ev2h_gemm_bf16(d, stream);
     const int tiles_m = ceil_div(d->M, BM);
     p.tiles_n = ceil_div(d->N, BN);
     p.nblk = tiles_m * p.tiles_n;

@@ -1,0 +1,240 @@
+// Dense layers on the bf16 matrix pipe: same contract as gemm.hip (ev2h_gemm), operands split on the fly.
+//   NS = 3 "bf16x3": X and W tiles are split exactly into three bf16 planes while they are staged into LDS
+//          (x = h + m + l, truncation split) and the 6 plane products hh, hm, mh, mm, hl, lh are accumulated
+//          in fp32 by v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy at 6/16 of the fp32 MFMA cost;
+//   NS = 1 plain bf16 (RNE) operands, fp32 accumulate.
+// 128x128x32 tiles, 8 waves (2 x 4), each wave 64 x 32 outputs (2 accumulator tiles); LDS rows hold the
+// NS planes side by side (NS*64 B + 16 B pad => conflict-free ds_read_b128); register prefetch of the
+// next K tile, two LDS buffers, one barrier per K tile.
+#include "common.hpp"
+#include "ev2hands_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB_BM = 128, GB_BN = 128, GB_BK = 32, GB_THREADS = 512;
+
+struct GemmBP {
+    const float* X; int ldx;
+    const float* W; int ldw;
+    float* Y; int ldy;
+    int M, N, K;
+    const float* bias; int bias_group_rows; int ldbias;
+    int relu;
+    const float* post_scale; const float* post_shift;
+    int taps; int Kc; int rows_per_seq;
+    int rowmax_rows;
+    int tiles_n; int nblk;
+};
+
+template <int NS>
+struct GBCfg {
+    static constexpr int RS = NS * 64 + 16;                 // bytes per LDS row (NS planes of 32 bf16 + pad)
+    static constexpr int OPER = GB_BM * RS;                 // one operand tile
+    static constexpr int LDS_BYTES = 4 * OPER;              // 2 buffers x (A, B)
+};
+
+__device__ __forceinline__ f32x16 gb_mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int NS>
+__device__ __forceinline__ void gb_split_pair(float x0, float x1, unsigned (&o)[NS]) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    if constexpr (NS == 1) {
+        const unsigned r0 = u0 + 0x7fffu + ((u0 >> 16) & 1u), r1 = u1 + 0x7fffu + ((u1 >> 16) & 1u);
+        o[0] = (r1 & 0xffff0000u) | (r0 >> 16);
+    } else {
+        o[0] = (u1 & 0xffff0000u) | (u0 >> 16);
+        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        o[1] = (v1 & 0xffff0000u) | (v0 >> 16);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        o[2] = (__float_as_uint(s1) & 0xffff0000u) | (__float_as_uint(s0) >> 16);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
+    using Cfg = GBCfg<NS>;
+    constexpr int RS = Cfg::RS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA0 = smem;
+    char* sB0 = smem + Cfg::OPER;
+    char* sA1 = smem + 2 * Cfg::OPER;
+    char* sB1 = smem + 3 * Cfg::OPER;
+
+    const int L = xcd_remap(blockIdx.x, p.nblk);
+    const int tn = L % p.tiles_n, tm = L / p.tiles_n;
+    const int m0 = tm * GB_BM, n0 = tn * GB_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // loader: thread -> (row = tid / 4, 8 consecutive k = (tid % 4) * 8) of the A tile and of the B tile
+    const int lrow = tid >> 2, lseg = tid & 3;
+    f32x4 ra[2], rb[2];
+
+    auto gload = [&](int kt) {
+        const int k = kt * GB_BK + lseg * 8;
+        int tap = 0, kc = k;
+        if (p.taps == 3) { tap = k / p.Kc; kc = k - tap * p.Kc; }
+        {
+            const int m = m0 + lrow;
+            bool ok = (m < p.M) && (k < p.K);
+            long src = m;
+            if (p.taps == 3) {
+                const int pos = m % p.rows_per_seq + tap - 1;
+                ok = ok && (pos >= 0) && (pos < p.rows_per_seq);
+                src = (long)m + tap - 1;
+            }
+            const long mm = ok ? src : 0;
+            const int kk = ok ? kc : 0;
+            const f32x4* g = reinterpret_cast<const f32x4*>(p.X + mm * p.ldx + kk);
+            f32x4 v0 = g[0], v1 = g[1];
+            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            ra[0] = v0; ra[1] = v1;
+        }
+        {
+            const int n = n0 + lrow;
+            const bool ok = (n < p.N) && (k < p.K);
+            const f32x4* g = reinterpret_cast<const f32x4*>(p.W + (long)(ok ? n : 0) * p.ldw + (ok ? k : 0));
+            f32x4 v0 = g[0], v1 = g[1];
+            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            rb[0] = v0; rb[1] = v1;
+        }
+    };
+    auto swrite_one = [&](char* dst, const f32x4 (&r)[2]) {
+        unsigned q[4][NS];
+        gb_split_pair<NS>(r[0][0], r[0][1], q[0]);
+        gb_split_pair<NS>(r[0][2], r[0][3], q[1]);
+        gb_split_pair<NS>(r[1][0], r[1][1], q[2]);
+        gb_split_pair<NS>(r[1][2], r[1][3], q[3]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
+            *reinterpret_cast<u32x4*>(dst + lrow * RS + s * 64 + lseg * 16) = v;
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int nk = (p.K + GB_BK - 1) / GB_BK;
+    gload(0);
+    swrite_one(sA0, ra);
+    swrite_one(sB0, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = (kt & 1) ? sA1 : sA0;
+        const char* sB = (kt & 1) ? sB1 : sB0;
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* pa = sA + (wm * 64 + l31) * RS + half * 16;
+        const char* pb = sB + (wn * 32 + l31) * RS + half * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u32x4 b[NS], a0[NS], a1[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                b[s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
+                a0[s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
+                a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
+            }
+            if constexpr (NS == 1) {
+                acc[0] = gb_mfma(a0[0], b[0], acc[0]);
+                acc[1] = gb_mfma(a1[0], b[0], acc[1]);
+            } else {
+                acc[0] = gb_mfma(a0[0], b[2], acc[0]); acc[1] = gb_mfma(a1[0], b[2], acc[1]);
+                acc[0] = gb_mfma(a0[2], b[0], acc[0]); acc[1] = gb_mfma(a1[2], b[0], acc[1]);
+                acc[0] = gb_mfma(a0[1], b[1], acc[0]); acc[1] = gb_mfma(a1[1], b[1], acc[1]);
+                acc[0] = gb_mfma(a0[0], b[1], acc[0]); acc[1] = gb_mfma(a1[0], b[1], acc[1]);
+                acc[0] = gb_mfma(a0[1], b[0], acc[0]); acc[1] = gb_mfma(a1[1], b[0], acc[1]);
+                acc[0] = gb_mfma(a0[0], b[0], acc[0]); acc[1] = gb_mfma(a1[0], b[0], acc[1]);
+            }
+        }
+        if (kt + 1 < nk) {
+            swrite_one((kt & 1) ? sA0 : sA1, ra);
+            swrite_one((kt & 1) ? sB0 : sB1, rb);
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue (fp32)
+    const float* bias = p.bias;
+    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
+    const int col = n0 + wn * 32 + l31;
+    const bool okc = col < p.N;
+    const float bj = (bias && okc) ? bias[col] : 0.f;
+    const float sj = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
+    const float tj = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
+    if (p.rowmax_rows == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                float v = acc[i][r] + bj;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.post_scale) v = __fmaf_rn(v, sj, tj);
+                if (row < p.M && okc) p.Y[(long)row * p.ldy + col] = v;
+            }
+    } else {
+        float* red = reinterpret_cast<float*>(smem);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                float v = acc[i][r] + bj;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.post_scale) v = __fmaf_rn(v, sj, tj);
+                if (row < p.M) mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (half == 0) red[wm * GB_BN + wn * 32 + l31] = mx;
+        __syncthreads();
+        if (tid < GB_BN) {
+            const int c = n0 + tid;
+            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GB_BN + tid]);
+        }
+    }
+}
+
+template <int NS>
+int launch_gb(const GemmBP& p, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GBCfg<NS>::LDS_BYTES));
+        attr_set = true;
+    }
+    gemm_nt_bf16_kernel<NS><<<p.nblk, GB_THREADS, GBCfg<NS>::LDS_BYTES, st>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+}  // namespace
+
+// called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
+int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG((d->K % 8) == 0);
+    GemmBP p{};
+    p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = d->Y; p.ldy = d->ldy;
+    p.M = d->M; p.N = d->N; p.taps = d->taps; p.Kc = d->K; p.K = d->K * d->taps;
+    p.rows_per_seq = d->rows_per_seq;
+    p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.ldbias = d->ldbias;
+    p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
+    p.rowmax_rows = d->rowmax_rows;
+    p.tiles_n = ceil_div(d->N, GB_BN);
+    p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
+    if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16) return launch_gb<1>(p, (hipStream_t)stream);
+    ev2h_set_error("ev2h_gemm: unknown precision %d", d->precision);
+    return EV2H_ERR_ARG;
+}

@@ -261,10 +261,14 @@ int launch_sa(const SaP& p, hipStream_t st) {
 
 }  // namespace
 
+int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream);
+
 extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
-    EV2H_CHECK_ARG(d && d->P1 && d->pts4 && d->ctr4 && d->gidx && d->W1x && d->W2 && d->b2 && d->W3 && d->b3 && d->out);
+    EV2H_CHECK_ARG(d && d->P1 && d->pts4 && d->ctr4 && d->gidx && d->W1x && d->b2 && d->b3 && d->out);
     EV2H_CHECK_ARG(d->B > 0 && d->S > 0 && d->Npts > 0 && d->K >= 32 && (d->K % 32) == 0);
     EV2H_CHECK_ARG((d->ldp % 4) == 0);
+    if (d->precision != EV2H_PREC_F32) return ev2h_sa_mlp_max_bf16(d, stream);
+    EV2H_CHECK_ARG(d->W2 && d->W3);
     SaP p{};
     p.P1 = d->P1; p.ldp = d->ldp; p.pts4 = (const float4*)d->pts4; p.ctr4 = (const float4*)d->ctr4; p.gidx = d->gidx;
     p.W1x = (const float4*)d->W1x; p.W2 = d->W2; p.b2 = d->b2; p.W3 = d->W3; p.b3 = d->b3;

@@ -1,0 +1,307 @@
+// Fused grouped set-abstraction MLP on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
+// rate), same structure and same reference lines as sa_mlp.hip (pointnet2_utils.py:244-257):
+//   NS = 3  "bf16x3": every fp32 operand is split exactly into three bf16 planes (8+8+8 mantissa bits,
+//           truncation split x = h + m + l) and the six products hh, hm, mh, mm, hl, lh are accumulated in
+//           fp32 -- dropped terms are O(2^-24), i.e. fp32-class accuracy at 6/16 of the fp32 MFMA cost;
+//   NS = 1  plain bf16 operands (round to nearest even), fp32 accumulate -- BASELINE.json config 3.
+// Layer 1 (gather + exact relative xyz + ReLU), all biases, ReLUs and the max stay in fp32.
+//
+// Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
+// ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
+// (global_load_lds_dwordx4, no staging registers); two buffers, one barrier per tile.
+#include "common.hpp"
+#include "ev2hands_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct SaBP {
+    const float* P1; int ldp;
+    const float4* pts4;
+    const float4* ctr4;
+    const int32_t* gidx;
+    const float4* W1x;
+    const char* W2s; const float* b2;     // bf16 tile images
+    const char* W3s; const float* b3;
+    float* out; int ldo;
+    int B, Npts, S, K;
+    int nblk;
+};
+
+constexpr int SAB_WAVES = 8;
+constexpr int SAB_THREADS = SAB_WAVES * 64;
+
+template <int C1, int C2, int C3, int NS>
+struct SaBCfg {
+    static constexpr int T2 = (C2 + 31) / 32;
+    static constexpr int REM = C2 % 32;
+    static constexpr int M_LAST = REM == 0 ? 2 : (REM <= 16 ? 1 : 2);   // live 16-wide k-blocks of the last layer-2 tile
+    static constexpr int C2P = 32 * (T2 - 1) + 16 * M_LAST;              // layer-3 contraction length (permuted order)
+    static constexpr int T3 = C3 / 32;
+    static constexpr int NC1 = C1 / 32;
+    static constexpr int RS2 = NS * 64 + 16;                             // bytes per row of a W2 chunk tile
+    static constexpr int RS3 = NS * C2P * 2 + 16;                        // bytes per row of a W3 tile
+    static constexpr int TB2 = T2 * 32 * RS2;
+    static constexpr int TB3 = 32 * RS3;
+    static constexpr int TILE = ((TB2 > TB3 ? TB2 : TB3) + 1023) / 1024 * 1024;
+    static constexpr int LDS_BYTES = 2 * TILE + C1 * 16 + T2 * 32 * 4;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// two fp32 -> packed bf16 pair(s): element 0 in the low half-word
+template <int NS>
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&o)[NS]) {
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    if constexpr (NS == 1) {
+        const unsigned r0 = u0 + 0x7fffu + ((u0 >> 16) & 1u), r1 = u1 + 0x7fffu + ((u1 >> 16) & 1u);   // RNE
+        o[0] = (r1 & 0xffff0000u) | (r0 >> 16);
+    } else {
+        // exact truncation split: x = h + m + l, each piece has <= 8 significant bits
+        o[0] = (u1 & 0xffff0000u) | (u0 >> 16);
+        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+        o[1] = (v1 & 0xffff0000u) | (v0 >> 16);
+        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+        o[2] = (__float_as_uint(s1) & 0xffff0000u) | (__float_as_uint(s0) >> 16);
+    }
+}
+
+// acc += sum over the kept plane products of A-plane x B-plane (smallest terms first)
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16 acc) {
+    if constexpr (NS == 1) {
+        return mfma_bf16(a[0], b[0], acc);
+    } else {
+        acc = mfma_bf16(a[0], b[2], acc);
+        acc = mfma_bf16(a[2], b[0], acc);
+        acc = mfma_bf16(a[1], b[1], acc);
+        acc = mfma_bf16(a[0], b[1], acc);
+        acc = mfma_bf16(a[1], b[0], acc);
+        return mfma_bf16(a[0], b[0], acc);
+    }
+}
+
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
+    using Cfg = SaBCfg<C1, C2, C3, NS>;
+    constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wt0 = smem;
+    char* wt1 = smem + Cfg::TILE;
+    float4* sW1x = reinterpret_cast<float4*>(smem + 2 * Cfg::TILE);
+    float* sb2 = reinterpret_cast<float*>(smem + 2 * Cfg::TILE + C1 * 16);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int L = xcd_remap(blockIdx.x, p.nblk);
+    const int ngroups = p.B * p.S;
+    const int g = L * SAB_WAVES + wave;
+    const bool valid = g < ngroups;
+    const int gg = valid ? g : ngroups - 1;
+    const int b = gg / p.S;
+
+    for (int i = tid; i < C1; i += SAB_THREADS) sW1x[i] = p.W1x[i];
+    for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i];
+
+    // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
+    auto dma_tile = [&](const char* src, char* dst, int bytes) {
+        for (int off = wave * 1024; off < bytes; off += SAB_WAVES * 1024) {
+            if (off + lane * 16 < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+        }
+    };
+    auto dma_w2 = [&](int c, char* dst) { dma_tile(p.W2s + (size_t)c * Cfg::TB2, dst, Cfg::TB2); };
+    auto dma_w3 = [&](int u, char* dst) { dma_tile(p.W3s + (size_t)u * Cfg::TB3, dst, Cfg::TB3); };
+
+    float mrun[T3];
+#pragma unroll
+    for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
+
+    const float4 ctr = p.ctr4[gg];
+    const int nstrips = p.K >> 5;
+    const int32_t* gi = p.gidx + (size_t)gg * p.K;
+
+    int buf = 0;
+    dma_w2(0, wt0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int strip = 0; strip < nstrips; ++strip) {
+        const int idx = gi[strip * 32 + l31];
+        const float4 q = p.pts4[(size_t)b * p.Npts + idx];
+        const float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
+        const float4* prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+        f32x4 raw[4];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+
+        // ---------------- layer 2 (contraction-chunk outer): h2[t] = D2[channel 32t + mfma_row(r,half)][neighbour]
+        f32x16 h2[T2];
+#pragma unroll
+        for (int t = 0; t < T2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h2[t][r] = 0.f;
+
+#pragma unroll 1
+        for (int c = 0; c < NC1; ++c) {
+            char* cur = buf ? wt1 : wt0;
+            char* nxt = buf ? wt0 : wt1;
+            if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt);
+            // layer-1 finish in fp32, then split: lane's channels 32c + 16*half + [0,16) = k-slots of 2 MFMAs
+            u32x4 bp[2][NS];
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                float hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 w = sW1x[32 * c + 16 * half + j4 * 4 + e];
+                    hv[e] = fmaxf(__fmaf_rn(w.z, dz, __fmaf_rn(w.y, dy, __fmaf_rn(w.x, dx, raw[j4][e]))), 0.f);
+                }
+                unsigned lo[NS], hi[NS];
+                split_pair<NS>(hv[0], hv[1], lo);
+                split_pair<NS>(hv[2], hv[3], hi);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    bp[j4 >> 1][s][(j4 & 1) * 2 + 0] = lo[s];
+                    bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
+                }
+            }
+            if (c + 1 < NC1) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
+            }
+            const char* pa = cur + l31 * RS2 + (16 * half) * 2;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int t = 0; t < T2; ++t) {
+                    u32x4 a[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t * RS2 + s * 64 + m * 16);
+                    h2[t] = mfma_split<NS>(a, bp[m], h2[t]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued above has landed
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        // bias + ReLU in fp32, then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
+        unsigned h2p[NS][T2][8];
+#pragma unroll
+        for (int t = 0; t < T2; ++t) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v0 = fmaxf(h2[t][2 * k] + sb2[32 * t + mfma_row(2 * k, half)], 0.f);
+                const float v1 = fmaxf(h2[t][2 * k + 1] + sb2[32 * t + mfma_row(2 * k + 1, half)], 0.f);
+                unsigned o[NS];
+                split_pair<NS>(v0, v1, o);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) h2p[s][t][k] = o[s];
+            }
+        }
+
+        // ---------------- layer 3 + max: D3[neighbour][channel] = H2 (A, registers) x W3 tile (B, LDS, permuted k order)
+#pragma unroll 1
+        for (int u = 0; u < T3; ++u) {
+            char* cur = buf ? wt1 : wt0;
+            char* nxt = buf ? wt0 : wt1;
+            const bool more_w3 = (u + 1 < T3);
+            const bool more = more_w3 || (strip + 1 < nstrips);
+            if (more_w3) dma_w3(u + 1, nxt); else if (more) dma_w2(0, nxt);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const char* pb = cur + l31 * RS3 + (8 * half) * 2;
+#pragma unroll
+            for (int t = 0; t < T2; ++t) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (t < T2 - 1 || m < Cfg::M_LAST) {
+                        u32x4 a[NS], w[NS];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            a[s][0] = h2p[s][t][4 * m + 0]; a[s][1] = h2p[s][t][4 * m + 1];
+                            a[s][2] = h2p[s][t][4 * m + 2]; a[s][3] = h2p[s][t][4 * m + 3];
+                            w[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (32 * t + 16 * m) * 2);
+                        }
+                        // operand roles swapped w.r.t. layer 2: activations are A, weights are B
+                        if constexpr (NS == 1) {
+                            acc = mfma_bf16(a[0], w[0], acc);
+                        } else {
+                            acc = mfma_bf16(a[0], w[2], acc);
+                            acc = mfma_bf16(a[2], w[0], acc);
+                            acc = mfma_bf16(a[1], w[1], acc);
+                            acc = mfma_bf16(a[0], w[1], acc);
+                            acc = mfma_bf16(a[1], w[0], acc);
+                            acc = mfma_bf16(a[0], w[0], acc);
+                        }
+                    }
+                }
+            }
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+#pragma unroll
+            for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int u = 0; u < T3; ++u) {
+        const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
+        if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v + p.b3[32 * u + l31], 0.f);
+    }
+}
+
+template <int C1, int C2, int C3, int NS>
+int launch_sab(const SaBP& p, hipStream_t st) {
+    using Cfg = SaBCfg<C1, C2, C3, NS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
+        attr_set = true;
+    }
+    sa_mlp_max_bf16_kernel<C1, C2, C3, NS><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+template <int NS>
+int dispatch_sab(const SaBP& p, int c1, int c2, int c3, hipStream_t st) {
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sab<32, 32, 64, NS>(p, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sab<64, 64, 128, NS>(p, st);
+    if (c1 == 64 && c2 == 96 && c3 == 128) return launch_sab<64, 96, 128, NS>(p, st);
+    if (c1 == 128 && c2 == 128 && c3 == 256) return launch_sab<128, 128, 256, NS>(p, st);
+    if (c1 == 128 && c2 == 196 && c3 == 256) return launch_sab<128, 196, 256, NS>(p, st);
+    ev2h_set_error("ev2h_sa_mlp_max: unsupported MLP widths %d-%d-%d", c1, c2, c3);
+    return EV2H_ERR_ARG;
+}
+
+}  // namespace
+
+// called by ev2h_sa_mlp_max when d->precision != EV2H_PREC_F32
+int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(d->W2s && d->W3s);
+    SaBP p{};
+    p.P1 = d->P1; p.ldp = d->ldp; p.pts4 = (const float4*)d->pts4; p.ctr4 = (const float4*)d->ctr4; p.gidx = d->gidx;
+    p.W1x = (const float4*)d->W1x; p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
+    p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
+    p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);
+    if (d->precision == EV2H_PREC_BF16) return dispatch_sab<1>(p, d->C1, d->C2, d->C3, st);
+    ev2h_set_error("ev2h_sa_mlp_max: unknown precision %d", d->precision);
+    return EV2H_ERR_ARG;
+}

@@ -93,6 +93,8 @@ class TEHNet(nn.Module):
         self.left_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.right_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.mhlnes = int(os.getenv("MHLNES", 0))
+        # arithmetic of the MFMA contractions: "f32" (exact), "bf16x3" (fp32-class, 3-plane split), "bf16"
+        self.precision = os.getenv("EV2H_PRECISION", "f32")
         self.left_query_conv = _query_conv()
         self.right_query_conv = _query_conv()
         self._packed = None
@@ -106,9 +108,9 @@ class TEHNet(nn.Module):
         return (str(ts[0].device), tuple((t.data_ptr(), t._version) for t in ts))
 
     def packed(self, device) -> PackedWeights:
-        key = (str(device), self._pack_key())
+        key = (str(device), self.precision, self._pack_key())
         if self._packed is None or self._packed_key != key:
-            self._packed = PackedWeights(self.state_dict(), device, self.in_channels)
+            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, self.precision)
             self._packed_key = key
         return self._packed
 

@@ -76,7 +76,7 @@ def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Te
 
 
 def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=None, post_shift=None, taps=1,
-          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None) -> torch.Tensor:
+          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32") -> torch.Tensor:
     """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1]."""
     M, ldx = X.shape
     N, ldw = W.shape
@@ -92,14 +92,16 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     d.relu = int(relu)
     d.post_scale, d.post_shift = _lib.ptr(post_scale), _lib.ptr(post_shift)
     d.taps, d.rows_per_seq, d.rowmax_rows = taps, rows_per_seq, rowmax_rows
+    d.precision = _lib.PREC[precision]
     L = _lib.lib()
     _lib.check(L.ev2h_init(), "ev2h_init")
     _lib.check(L.ev2h_gemm(C.byref(d), _st()), "ev2h_gemm")
     return Y
 
 
-def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int) -> torch.Tensor:
-    """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3]."""
+def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32") -> torch.Tensor:
+    """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3].
+    W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); bf16 tile images are built here when needed."""
     B, Npts, C1 = P1.shape
     S, K = gidx.shape[1], gidx.shape[2]
     C3 = W3.shape[0]
@@ -109,6 +111,14 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int) -> torch.Tens
     d.W1x, d.W2, d.b2, d.W3, d.b3 = W1x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr()
     d.out, d.ldo = out.data_ptr(), C3
     d.B, d.Npts, d.S, d.K, d.C1, d.C2, d.C3 = B, Npts, S, K, C1, C2, C3
+    d.precision = _lib.PREC[precision]
+    keep = []
+    if precision != "f32":
+        from .pack import sa_bf16_images
+        i2, i3 = sa_bf16_images(W2[:C2].detach().cpu().double().numpy(), W3[:, :C2].detach().cpu().double().numpy(),
+                                {"bf16": 1, "bf16x3": 3}[precision])
+        keep = [torch.from_numpy(i2).to(P1.device), torch.from_numpy(i3).to(P1.device)]
+        d.W2s, d.W3s = keep[0].data_ptr(), keep[1].data_ptr()
     _lib.check(_lib.lib().ev2h_sa_mlp_max(C.byref(d), _st()), "ev2h_sa_mlp_max")
     return out
 

@@ -56,16 +56,73 @@ def _up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+def split_bf16_planes(a: np.ndarray, ns: int):
+    """fp32 array -> list of `ns` uint16 arrays of bf16 bit patterns.
+    ns == 1: round to nearest even.  ns == 3: exact truncation split a = h + m + l (8 + 8 + 8 mantissa bits),
+    the same split the kernels apply to activations (csrc/sa_mlp_bf16.hip: split_pair)."""
+    x = np.ascontiguousarray(a, dtype=np.float32)
+    if ns == 1:
+        u = x.view(np.uint32).astype(np.uint64)
+        return [((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)]
+    planes, r = [], x.copy()
+    for _ in range(ns):
+        u = r.view(np.uint32) & np.uint32(0xFFFF0000)
+        planes.append((u >> np.uint32(16)).astype(np.uint16))
+        r = (r - u.view(np.float32)).astype(np.float32)        # exact: the difference has fewer significant bits
+    return planes
+
+
+def sa_bf16_geometry(C2: int):
+    T2 = _up(C2, 32) // 32
+    rem = C2 % 32
+    m_last = 2 if rem == 0 else (1 if rem <= 16 else 2)
+    return T2, 32 * (T2 - 1) + 16 * m_last
+
+
+def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
+    """Byte images of the LDS weight tiles of sa_mlp_max_bf16_kernel (see SaBCfg in csrc/sa_mlp_bf16.hip).
+    W2 [C2, C1], W3 [C3, C2] folded fp32 weights.  Returns (W2s, W3s) uint8 arrays."""
+    C2, C1 = W2.shape
+    C3 = W3.shape[0]
+    T2, C2P = sa_bf16_geometry(C2)
+    W2p = _pad(W2, T2 * 32, C1)
+    p2 = split_bf16_planes(W2p, ns)
+    rs2 = ns * 64 + 16
+    img2 = np.zeros((C1 // 32, T2 * 32, rs2), dtype=np.uint8)
+    for c in range(C1 // 32):
+        for s_ in range(ns):
+            blk = np.ascontiguousarray(p2[s_][:, 32 * c:32 * c + 32])               # [rows, 32] uint16
+            img2[c, :, s_ * 64:(s_ + 1) * 64] = blk.view(np.uint8).reshape(T2 * 32, 64)
+    # layer-3 contraction order follows the MFMA D layout of layer 2: position 32t+16m+8h+e <-> channel 32t+16m+4h+(e&3)+8(e>>2)
+    pos = np.arange(C2P)
+    t, w_ = pos // 32, pos % 32
+    m, h, e = w_ // 16, (w_ % 16) // 8, w_ % 8
+    ch = 32 * t + 16 * m + 4 * h + (e & 3) + 8 * (e >> 2)
+    W3p = np.zeros((C3, C2P), dtype=np.float64)
+    ok = ch < C2
+    W3p[:, ok] = W3[:, ch[ok]]
+    p3 = split_bf16_planes(W3p, ns)
+    rs3 = ns * C2P * 2 + 16
+    img3 = np.zeros((C3 // 32, 32, rs3), dtype=np.uint8)
+    for s_ in range(ns):
+        blk = p3[s_].view(np.uint8).reshape(C3 // 32, 32, C2P * 2)
+        img3[:, :, s_ * C2P * 2:(s_ + 1) * C2P * 2] = blk
+    return img2.reshape(-1), img3.reshape(-1)
+
+
 class PackedWeights:
     """Owns the device tensors and the ev2h_weights struct that points at them."""
 
-    def __init__(self, sd: dict, device, in_channels: int):
+    def __init__(self, sd: dict, device, in_channels: int, precision: str = "f32"):
         self.device = torch.device(device)
         self.in_channels = in_channels
+        self.precision = precision
+        self.ns = {"f32": 0, "bf16": 1, "bf16x3": 3}[precision]
         self._keep = []
         self.tensors = {}
         self.struct = _lib.Weights()
         w = self.struct
+        w.precision = _lib.PREC[precision]
         self._sa_module(w.sa1, sd, "sa1", in_channels, 8, synth.SA1_NPOINT, synth.SA1_RADII, synth.SA1_NSAMPLE)
         self._sa_module(w.sa2, sd, "sa2", 320, 320, synth.SA2_NPOINT, synth.SA2_RADII, synth.SA2_NSAMPLE)
         for h, side in enumerate(("left", "right")):
@@ -118,6 +175,12 @@ class PackedWeights:
         self.tensors[name] = t
         return t.data_ptr()
 
+    def _dev_bytes(self, name: str, a: np.ndarray) -> int:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(self.device)
+        self._keep.append(t)
+        self.tensors[name] = t
+        return t.data_ptr()
+
     def _dense(self, d, name, W, b, post_scale=None, post_shift=None, K=None):
         O, Kfull = W.shape
         ldw = _up(Kfull, 4)
@@ -159,6 +222,10 @@ class PackedWeights:
             br.W3 = self._dev(n + ".W3", _pad(Ws[2], C3, _up(C2, 8)))
             br.b3 = self._dev(n + ".b3", bs[2])
             br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, K, float(r)
+            if self.ns:
+                i2, i3 = sa_bf16_images(Ws[1], Ws[2], self.ns)
+                br.W2s = self._dev_bytes(n + ".W2s", i2)
+                br.W3s = self._dev_bytes(n + ".W3s", i3)
         m.W1f = self._dev(prefix + ".W1f", np.concatenate(W1f, 0))
         m.b1 = self._dev(prefix + ".b1", np.concatenate(b1, 0))
 

@@ -31,6 +31,15 @@ extern "C" {
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
+/* Arithmetic of the MFMA contractions (selections, biases, ReLU, max, MANO are always fp32):
+ *  F32     v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (default);
+ *  BF16X3  each fp32 operand split exactly into 3 bf16 planes, 6 plane products on
+ *          v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class accuracy (dropped terms O(2^-24));
+ *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3). */
+#define EV2H_PREC_F32 0
+#define EV2H_PREC_BF16 1
+#define EV2H_PREC_BF16X3 3
+
 /* ---- library ------------------------------------------------------------------------------- */
 int ev2h_abi_version(void);
 const char* ev2h_last_error(void);
@@ -83,6 +92,7 @@ typedef struct ev2h_gemm_desc {
     int taps;                    /* 1, or 3 = Conv1d(k=3, padding=1) along rows, zero padded per sequence */
     int rows_per_seq;            /* rows per window when taps == 3                                      */
     int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
+    int precision;               /* EV2H_PREC_*; BF16 / BF16X3 need K % 8 == 0 (operands are split on the fly) */
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 
@@ -107,6 +117,9 @@ typedef struct ev2h_sa_desc {
     float* out; int ldo;         /* [B][S][ldo], C3 columns written                                     */
     int B, Npts, S, K;           /* K multiple of 32                                                    */
     int C1, C2, C3;
+    int precision;               /* EV2H_PREC_*                                                         */
+    const void* W2s;             /* bf16 tile images of W2 / W3 for BF16 / BF16X3 (ev2hands_amd/pack.py), */
+    const void* W3s;             /* NULL for F32                                                        */
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
@@ -140,6 +153,7 @@ typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;
     int C1, C2, C3, K;
     float radius;
+    const void* W2s; const void* W3s;   /* bf16 tile images (NULL unless precision != F32) */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
@@ -167,6 +181,7 @@ typedef struct ev2h_weights {
     ev2h_dense qconv4[2];
     ev2h_dense mano_sa2[2][2];
     ev2h_dense head0[2], head4[2];
+    int precision;                               /* EV2H_PREC_* used by the MFMA kernels               */
 } ev2h_weights;
 
 typedef struct ev2h_outputs {

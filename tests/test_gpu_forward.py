@@ -27,9 +27,10 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def make_net(C, seed, device="cuda:0"):
+def make_net(C, seed, device="cuda:0", precision="f32"):
     from ev2hands_amd.model import TEHNetWrapper
     os.environ["ERPC"] = "1" if C == 5 else "0"
+    os.environ["EV2H_PRECISION"] = precision
     assets = {s: synth.synth_mano_assets(s, seed) for s in ("left", "right")}
     sd = synth.synth_state_dict(C, seed)
     net = TEHNetWrapper(device, mano_assets=assets)
@@ -96,11 +97,13 @@ def check_against(out, net, ref, trace, B, N):
     assert same
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("kind,C,N,B,seed", [("U", 4, 2048, 2, 0), ("E", 5, 2048, 2, 1), ("E", 4, 2048, 3, 4), ("U", 5, 256, 2, 2),
                                               ("E", 4, 8192, 1, 5), ("U", 5, 1000, 2, 6)])
-def test_forward_matches_oracle(kind, C, N, B, seed):
+def test_forward_matches_oracle(kind, C, N, B, seed, precision):
+    """Both fp32-class arithmetic modes must meet the full parity bar (1e-4, argmax and selections exact)."""
     _need_gpu()
-    net, sd, assets = make_net(C, seed)
+    net, sd, assets = make_net(C, seed, precision=precision)
     xyz = synth.synth_cloud(kind, B, C, N, seed)
     inits = synth.fps_inits(B, N, seed)
     ref, trace = run_oracle(sd, assets, xyz, inits)
@@ -114,13 +117,14 @@ def test_forward_matches_oracle(kind, C, N, B, seed):
     check_against(out, net, ref, trace, B, N)
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
-def test_forward_matches_reference_fixture(path):
+def test_forward_matches_reference_fixture(path, precision):
     """Against numbers produced by the reference itself (oracle/make_golden.py)."""
     _need_gpu()
     g = np.load(path)
     B, C, N, seed = [int(v) for v in g["meta"]]
-    net, sd, assets = make_net(C, seed)
+    net, sd, assets = make_net(C, seed, precision=precision)
     xyz = torch.from_numpy(g["xyz"])
     inits = [torch.from_numpy(g["fps_init"][i].astype(np.int64)) for i in range(4)]
     net.net.fps_init = inits
@@ -200,3 +204,27 @@ def test_training_forward_is_refused():
     net.train()
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1, 4, 256, device="cuda"))
+
+
+def test_bf16_mode_reports_mpjpe_and_argmax_agreement():
+    """BASELINE.json config 3: plain-bf16 MFMA operands (selection math stays fp32).  Not a parity mode:
+    report root-relative MPJPE (mm, formula of evaluate_ev2hands_r.py:43-54) and argmax agreement vs fp32."""
+    _need_gpu()
+    B, C, N, seed = 4, 4, 2048, 2
+    xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    outs = {}
+    for prec in ("f32", "bf16"):
+        net, sd, assets = make_net(C, seed, precision=prec)
+        net.net.fps_init = inits
+        with torch.no_grad():
+            o = net(xyz)
+        outs[prec] = {"logits": o["class_logits"].clone(), "j": torch.cat([o["left"]["j3d"], o["right"]["j3d"]], 1).clone()}
+    os.environ["EV2H_PRECISION"] = "f32"
+    a, b = outs["f32"]["j"], outs["bf16"]["j"]
+    a = a - a[:, :1]
+    b = b - b[:, :1]
+    mpjpe_mm = float((a - b).norm(dim=-1).mean() * 1000)
+    agree = float((outs["f32"]["logits"].argmax(1) == outs["bf16"]["logits"].argmax(1)).float().mean())
+    print(f"bf16 vs fp32: root-relative MPJPE {mpjpe_mm:.4f} mm over 42 joints, argmax agreement {agree * 100:.3f} %")
+    assert mpjpe_mm < 5.0 and agree > 0.97

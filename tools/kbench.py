@@ -21,7 +21,7 @@ def timeit(fn, iters=5, warm=2):
     return s.elapsed_time(e) / iters
 
 
-def bench_sa(B=256):
+def bench_sa(B=256, precision="f32"):
     up = lambda x, m: (x + m - 1) // m * m
     for (C1, C2, C3, K, S, Npts, tag) in [(32, 32, 64, 32, 512, 2048, "enc.sa1.0"), (64, 64, 128, 64, 512, 2048, "enc.sa1.1"),
                                           (64, 96, 128, 128, 512, 2048, "enc.sa1.2"), (128, 128, 256, 64, 128, 2048, "mano.0"),
@@ -36,12 +36,28 @@ def bench_sa(B=256):
         b2 = torch.randn(up(C2, 32), device=d)
         W3 = torch.randn(C3, up(C2, 8), device=d) * C2 ** -0.5
         b3 = torch.randn(C3, device=d)
-        ms = timeit(lambda: ops.sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2))
+        if precision == "f32":
+            fn = lambda: ops.sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2)
+        else:
+            import ctypes as C
+            from ev2hands_amd import _lib
+            from ev2hands_amd.pack import sa_bf16_images
+            i2, i3 = sa_bf16_images(W2[:C2].cpu().double().numpy(), W3[:, :C2].cpu().double().numpy(), {"bf16": 1, "bf16x3": 3}[precision])
+            i2, i3 = torch.from_numpy(i2).cuda(), torch.from_numpy(i3).cuda()
+            out = torch.empty(B, S, C3, device=d)
+            dd = _lib.SaDesc()
+            dd.P1, dd.ldp, dd.pts4, dd.ctr4, dd.gidx = P1.data_ptr(), C1, pts4.data_ptr(), ctr4.data_ptr(), gidx.data_ptr()
+            dd.W1x, dd.b2, dd.b3, dd.W2s, dd.W3s = W1x.data_ptr(), b2.data_ptr(), b3.data_ptr(), i2.data_ptr(), i3.data_ptr()
+            dd.out, dd.ldo = out.data_ptr(), C3
+            dd.B, dd.Npts, dd.S, dd.K, dd.C1, dd.C2, dd.C3, dd.precision = B, Npts, S, K, C1, C2, C3, _lib.PREC[precision]
+            L = _lib.lib()
+            fn = lambda: _lib.check(L.ev2h_sa_mlp_max(C.byref(dd), _lib.stream_handle()), "sa")
+        ms = timeit(fn)
         flop = 2.0 * B * S * K * (C1 * C2 + C2 * C3)
-        print(f"sa<{C1},{C2},{C3}> K={K} S={S} {tag:10s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
+        print(f"[{precision}] sa<{C1},{C2},{C3}> K={K} S={S} {tag:10s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
 
 
-def bench_gemm(B=256, N=2048):
+def bench_gemm(B=256, N=2048, precision="f32"):
     R = B * N
     for (M, Nn, K, taps, tag) in [(R, 512, 256, 3, "qconv0"), (R, 256, 256, 3, "qconv4"), (R, 256, 128, 1, "fp1.2"), (R, 128, 128, 1, "fp1.0"),
                                   (R, 256, 256, 1, "cls0"), (R, 4, 256, 1, "cls4"), (R, 160, 8, 1, "P1a"), (R, 256, 8, 1, "P1m"),
@@ -50,14 +66,20 @@ def bench_gemm(B=256, N=2048):
         X = torch.randn(M, K, device="cuda")
         W = torch.randn(Nn, K * taps, device="cuda") * (K * taps) ** -0.5
         b = torch.randn(Nn, device="cuda")
-        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K))
+        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K, precision=precision))
         flop = 2.0 * M * Nn * K * taps
-        print(f"gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
+        print(f"[{precision}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
 
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("sa", "all"):
         bench_sa()
+    if what in ("sab", "all"):
+        bench_sa(precision="bf16x3")
+        bench_sa(precision="bf16")
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("gemmb", "all"):
+        bench_gemm(precision="bf16x3")
+        bench_gemm(precision="bf16")
