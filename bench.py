@@ -28,6 +28,12 @@ if ROOT not in sys.path:
 from ev2hands_amd import _lib, dist as evdist, synth  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same table, dense bf16 matrix peak
+# plane products executed per algorithmic multiply-add in each arithmetic mode
+PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16": 1}
+DTYPE = {"f32": "f32",
+         "bf16x3": "f32 (each f32 operand split exactly into 3 bf16 planes, 6 plane products per MAC on the bf16 MFMA, f32 accumulate)",
+         "bf16": "bf16 (f32 accumulate)"}
 # algorithmic work of the profiled kernel per window: layers 2+3 of mano.sa1 branch 1
 # (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
 PROFILED_TAG = "manoR.1"
@@ -43,8 +49,10 @@ def parse():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--cloud", default="E", choices=["U", "E"])
-    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f32"), choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the MFMA contractions (f32 exact | bf16x3 fp32-class split | bf16)")
+    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the MFMA contractions: bf16x3 = fp32-class 3-plane split (default, passes the "
+                         "1e-4 / exact-argmax parity bar), f32 = v_mfma_f32_32x32x2_f32, bf16 = reduced precision (config 3)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra exact-f32-MFMA timing leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -74,15 +82,16 @@ class HipEvents:
         return out
 
 
-def pmc_traffic():
+def pmc_traffic(precision="f32"):
     """HBM bytes per launch of the profiled kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_hbm_traffic_*.json: (2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction); None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_*.json")))
     if not files:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"]["sa_mlp_max_kernel<128, 196, 256>"]
+        ks = json.load(open(files[-1]))["kernels"]
+        k = ks[[n for n in ks if "128, 196, 256" in n][0]]
         return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch_corrected"], "source": os.path.basename(files[-1])}
     except Exception:
         return None
@@ -161,27 +170,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(nsteps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        sync()
+        dt_ = time.perf_counter() - t0
+        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
     for _ in range(a.warmup):
         step()
     sync()
     L.ev2h_profile_set(PROFILED_TAG.encode(), ev.start, ev.stop, nprof)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
+    dt = timed(a.steps)
     L.ev2h_profile_set(None, None, None, 0)
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    # transparency leg: the same workload with exact f32 MFMA arithmetic (not part of `value`)
+    f32_leg = None
+    if a.precision != "f32" and not a.no_f32_leg:
+        net.net.precision = "f32"
+        for _ in range(max(1, a.warmup)):
+            step()
+        k = max(2, a.steps // 2)
+        dtf = timed(k)
+        f32_leg = {"value": round(gB * k / dtf, 2), "ms_per_step": round(dtf / k * 1e3, 3), "steps": k,
+                   "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+        net.net.precision = a.precision
 
     if rank == 0:
         kms = ev.elapsed_ms(a.steps)
         kavg = sum(kms) / max(len(kms), 1)
-        flops = 2.0 * PROFILED_MAC_PER_WINDOW * B
+        nprod = PRODUCTS[a.precision]
+        peak = PEAK_F32_MFMA_TFLOPS if a.precision == "f32" else PEAK_BF16_MFMA_TFLOPS
+        alg_flops = 2.0 * PROFILED_MAC_PER_WINDOW * B            # fp32 multiply-adds of the layer, x2
+        flops = alg_flops * nprod                                # MFMA flops the arithmetic mode needs for them
         ach = flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
         res = {
             "metric": "event-windows/sec at B=256 N=2048",
@@ -190,16 +217,19 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
                                    f"random-init 342-key checkpoint, synthetic MANO-shaped assets",
-                       "global_batch": gB, "points": N, "channels": Cc,
+                       "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch)",
-                         "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(),
-                         "kernel_ms": round(kavg, 4), "flop_per_launch": flops},
+            "roofline": {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch, {a.precision})",
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": pmc_traffic(a.precision),
+                         "kernel_ms": round(kavg, 4), "flop_per_launch": flops,
+                         "products_per_mac": nprod, "fp32_equivalent_tflops": round(ach / nprod, 2)},
         }
+        if f32_leg:
+            res["f32_mfma_leg"] = f32_leg
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         print(json.dumps(res), flush=True)

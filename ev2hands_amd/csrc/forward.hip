@@ -209,6 +209,7 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     d.relu = relu; d.post_scale = w.post_scale; d.post_shift = w.post_shift;
     d.taps = taps; d.rows_per_seq = rows_per_seq; d.rowmax_rows = rowmax_rows;
     d.precision = g_precision;
+    d.Ws = (g_precision != EV2H_PREC_F32) ? w.Ws : nullptr;
     return ev2h_gemm(&d, st);
 }
 

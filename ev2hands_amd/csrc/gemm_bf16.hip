@@ -6,6 +6,8 @@
 // 128x128x32 tiles, 8 waves (2 x 4), each wave 64 x 32 outputs (2 accumulator tiles); LDS rows hold the
 // NS planes side by side (NS*64 B + 16 B pad => conflict-free ds_read_b128); register prefetch of the
 // next K tile, two LDS buffers, one barrier per K tile.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "ev2hands_hip.h"
 
@@ -27,6 +29,7 @@ struct GemmBP {
     int taps; int Kc; int rows_per_seq;
     int rowmax_rows;
     int tiles_n; int nblk;
+    int debug;              // timing experiments only (EV2H_GEMM_DEBUG): bit0 skip W DMA after tile 0, bit1 skip X loads
 };
 
 template <int NS>
@@ -219,6 +222,204 @@ int launch_gb(const GemmBP& p, hipStream_t st) {
     return EV2H_OK;
 }
 
+// ---------------------------------------------------------------------------------------- wide tile, pre-split W
+// 128 x 256 x 32 tiles for the big layers (N >= 192): W arrives as host-packed bf16 plane images of the LDS
+// tile (ev2hands_amd/pack.py: gemm_bf16_w_image) and is streamed by LDS-DMA; only X is split on the fly.
+// 8 waves as 2 x 4, each wave 64 x 64 = 2 x 2 accumulator tiles: 12 fragment reads feed 24 MFMAs.
+constexpr int GW_BN = 256;
+
+template <int NS>
+struct GWCfg {
+    static constexpr int RS = NS * 64 + 16;
+    static constexpr int A_BYTES = GB_BM * RS;
+    static constexpr int B_BYTES = GW_BN * RS;
+    static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
+};
+
+template <int NS>
+__global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP p, const char* __restrict__ Ws) {
+    using Cfg = GWCfg<NS>;
+    constexpr int RS = Cfg::RS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA0 = smem;
+    char* sA1 = smem + Cfg::A_BYTES;
+    char* sB0 = smem + 2 * Cfg::A_BYTES;
+    char* sB1 = sB0 + Cfg::B_BYTES;
+
+    const int L = xcd_remap(blockIdx.x, p.nblk);
+    const int tn = L % p.tiles_n, tm = L / p.tiles_n;
+    const int m0 = tm * GB_BM, n0 = tn * GW_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lrow = tid >> 2, lseg = tid & 3;
+    const int nk = (p.K + GB_BK - 1) / GB_BK;
+    f32x4 ra[2];             // X rows of the next K tile, in flight while the current tile is multiplied
+    bool oka = true;         // zero fill is applied when the tile is written to LDS, not on the load
+
+    auto gload = [&](int kt) {
+        const int k = kt * GB_BK + lseg * 8;
+        int tap = 0, kc = k;
+        if (p.taps == 3) { tap = k / p.Kc; kc = k - tap * p.Kc; }
+        const int m = m0 + lrow;
+        bool ok = (m < p.M) && (k < p.K);
+        long src = m;
+        if (p.taps == 3) {
+            const int pos = m % p.rows_per_seq + tap - 1;
+            ok = ok && (pos >= 0) && (pos < p.rows_per_seq);
+            src = (long)m + tap - 1;
+        }
+        const float* g = p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0);
+        // Issued from inline asm: once an LDS-DMA is in flight hipcc waits vmcnt(0) at (and before) every ordinary
+        // load it tracks, which would make the DMA synchronous.  These loads are waited for by hand (wait_all).
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                     : "=&v"(ra[0]), "=&v"(ra[1]) : "v"(g) : "memory");
+        oka = ok;
+    };
+    auto wait_all = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]) : : "memory"); };
+    auto swrite = [&](char* dst) {
+        f32x4 r[2] = {ra[0], ra[1]};
+        if (!oka) { r[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[1] = r[0]; }
+        unsigned q[4][NS];
+        gb_split_pair<NS>(r[0][0], r[0][1], q[0]);
+        gb_split_pair<NS>(r[0][2], r[0][3], q[1]);
+        gb_split_pair<NS>(r[1][0], r[1][1], q[2]);
+        gb_split_pair<NS>(r[1][2], r[1][3], q[3]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
+            *reinterpret_cast<u32x4*>(dst + lrow * RS + s * 64 + lseg * 16) = v;
+        }
+    };
+    auto dma_b = [&](int kt, char* dst) {
+        const char* src = Ws + ((size_t)tn * nk + kt) * Cfg::B_BYTES;
+        for (int off = wave * 1024; off < Cfg::B_BYTES; off += 8 * 1024)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+    };
+    static_assert(Cfg::B_BYTES % 1024 == 0, "B tile image must be a whole number of 1 KiB DMA pieces");
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    dma_b(0, sB0);
+    gload(0);
+    wait_all();
+    swrite(sA0);
+    __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* sA = (kt & 1) ? sA1 : sA0;
+        const char* sB = (kt & 1) ? sB1 : sB0;
+        const bool more = kt + 1 < nk;
+        if (more) {                     // next tile: W by LDS-DMA, X rows into registers; both land under the MFMAs
+            if (!(p.debug & 1)) dma_b(kt + 1, (kt & 1) ? sB0 : sB1);
+            if (!(p.debug & 2)) gload(kt + 1);
+        }
+        const char* pa = sA + (wm * 64 + l31) * RS + half * 16;
+        const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u32x4 a[2][NS], b[2][NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a[0][s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
+                a[1][s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
+                b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
+                b[1][s] = *reinterpret_cast<const u32x4*>(pb + 32 * RS + s * 64 + m * 32);
+            }
+            // plane-product outer, accumulator inner: consecutive MFMAs never depend on each other
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = (NS == 1 ? 5 : 0); q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = gb_mfma(a[i][NS == 1 ? 0 : PA[q]], b[j][NS == 1 ? 0 : PB[q]], acc[i][j]);
+        }
+        if (more) {
+            wait_all();                 // X rows (and, being older, the DMA pieces of this wave) have landed
+            swrite((kt & 1) ? sA0 : sA1);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);     // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    const float* bias = p.bias;
+    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
+    float bj[2], sj[2], tj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool okc = col < p.N;
+        bj[j] = (bias && okc) ? bias[col] : 0.f;
+        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
+        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
+    }
+    if (p.rowmax_rows == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                    float v = acc[i][j][r] + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
+                }
+            }
+    } else {
+        float* red = reinterpret_cast<float*>(smem);
+        float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                    float v = acc[i][j][r] + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if (row < p.M) mx[j] = fmaxf(mx[j], v);
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
+        if (half == 0) {
+            red[wm * GW_BN + wn * 64 + l31] = mx[0];
+            red[wm * GW_BN + wn * 64 + 32 + l31] = mx[1];
+        }
+        __syncthreads();
+        if (tid < GW_BN) {
+            const int c = n0 + tid;
+            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GW_BN + tid]);
+        }
+    }
+}
+
+template <int NS>
+int launch_gw(const GemmBP& p, const char* Ws, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_wide_kernel<NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GWCfg<NS>::LDS_BYTES));
+        attr_set = true;
+    }
+    gemm_nt_bf16_wide_kernel<NS><<<p.nblk, GB_THREADS, GWCfg<NS>::LDS_BYTES, st>>>(p, Ws);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
 }  // namespace
 
 // called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
@@ -231,6 +432,14 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.ldbias = d->ldbias;
     p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
     p.rowmax_rows = d->rowmax_rows;
+    static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
+    p.debug = dbg;
+    if (d->Ws) {   // host-packed plane images of W: wide tile, W streamed by LDS-DMA
+        p.tiles_n = ceil_div(d->N, GW_BN);
+        p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
+        if (d->precision == EV2H_PREC_BF16X3) return launch_gw<3>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_BF16) return launch_gw<1>(p, (const char*)d->Ws, (hipStream_t)stream);
+    }
     p.tiles_n = ceil_div(d->N, GB_BN);
     p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
     if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3>(p, (hipStream_t)stream);

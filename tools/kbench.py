@@ -66,7 +66,8 @@ def bench_gemm(B=256, N=2048, precision="f32"):
         X = torch.randn(M, K, device="cuda")
         W = torch.randn(Nn, K * taps, device="cuda") * (K * taps) ** -0.5
         b = torch.randn(Nn, device="cuda")
-        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K, precision=precision))
+        wi = ops.make_w_image(W, precision) if (precision != "f32" and Nn >= 192) else None
+        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K, precision=precision, w_image=wi))
         flop = 2.0 * M * Nn * K * taps
         print(f"[{precision}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
 
