@@ -47,6 +47,7 @@ struct SaBCfg {
     static constexpr int TB3 = 32 * RS3;
     static constexpr int TILE = ((TB2 > TB3 ? TB2 : TB3) + 1023) / 1024 * 1024;
     static constexpr int LDS_BYTES = 2 * TILE + C1 * 16 + T2 * 32 * 4;
+    static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -154,6 +155,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             char* cur = buf ? wt1 : wt0;
             char* nxt = buf ? wt0 : wt1;
             if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt);
+            if (!Cfg::PREFETCH_P1 && c > 0) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
+            }
             // layer-1 finish in fp32, then split: lane's channels 32c + 16*half + [0,16) = k-slots of 2 MFMAs
             u32x4 bp[2][NS];
 #pragma unroll
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
                 }
             }
-            if (c + 1 < NC1) {
+            if (Cfg::PREFETCH_P1 && c + 1 < NC1) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
             }
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
 
         // bias + ReLU in fp32, then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
-        unsigned h2p[NS][T2][8];
+        u32x4 h2p[NS][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
 #pragma unroll
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 unsigned o[NS];
                 split_pair<NS>(v0, v1, o);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) h2p[s][t][k] = o[s];
+                for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
         }
 
@@ -228,8 +233,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         u32x4 a[NS], w[NS];
 #pragma unroll
                         for (int s = 0; s < NS; ++s) {
-                            a[s][0] = h2p[s][t][4 * m + 0]; a[s][1] = h2p[s][t][4 * m + 1];
-                            a[s][2] = h2p[s][t][4 * m + 2]; a[s][3] = h2p[s][t][4 * m + 3];
+                            a[s] = h2p[s][t][m];
                             w[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (32 * t + 16 * m) * 2);
                         }
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
