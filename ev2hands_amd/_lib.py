@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
                 ("M", ci), ("N", ci), ("K", ci),
                 ("bias", vp), ("bias_group_rows", ci), ("ldbias", ci), ("relu", ci),
                 ("post_scale", vp), ("post_shift", vp),
-                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp)]
+                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci)]
 
 
 class SaDesc(C.Structure):
@@ -41,7 +41,7 @@ class SaModule(C.Structure):
 
 
 class Dense(C.Structure):
-    _fields_ = [("W", vp), ("b", vp), ("post_scale", vp), ("post_shift", vp), ("O", ci), ("K", ci), ("ldw", ci), ("Ws", vp)]
+    _fields_ = [("W", vp), ("b", vp), ("post_scale", vp), ("post_shift", vp), ("O", ci), ("K", ci), ("ldw", ci), ("Ws", vp), ("ws_tile_rows", ci)]
 
 
 class Weights(C.Structure):

@@ -210,6 +210,7 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     d.taps = taps; d.rows_per_seq = rows_per_seq; d.rowmax_rows = rowmax_rows;
     d.precision = g_precision;
     d.Ws = (g_precision != EV2H_PREC_F32) ? w.Ws : nullptr;
+    d.ws_tile_rows = w.ws_tile_rows;
     return ev2h_gemm(&d, st);
 }
 

@@ -420,6 +420,196 @@ int launch_gw(const GemmBP& p, const char* Ws, hipStream_t st) {
     return EV2H_OK;
 }
 
+// ---------------------------------------------------------------------------------------- occupancy variant
+// 128 x 128 x 32 tiles, 4 waves (2 x 2, each 64 x 64), ONE LDS buffer (53 KB at NS = 3) so that three
+// independent workgroups share a CU: while one sits at its barrier or stages the next K tile, the other two
+// keep the matrix pipe busy (the barrier/refill bubble of a lone 8-wave workgroup costs 12-20 % here, see
+// tools/ubench/mfma_lds.hip).  W arrives as 128-row plane images by LDS-DMA, X is split on the fly.
+constexpr int GO_BN = 128, GO_THREADS = 256;
+
+template <int NS>
+struct GOCfg {
+    static constexpr int RS = NS * 64 + 16;
+    static constexpr int A_BYTES = GB_BM * RS;
+    static constexpr int B_BYTES = GO_BN * RS;
+    static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
+};
+
+template <int NS>
+__global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP p, const char* __restrict__ Ws) {
+    using Cfg = GOCfg<NS>;
+    constexpr int RS = Cfg::RS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sB = smem + Cfg::A_BYTES;
+
+    const int L = xcd_remap(blockIdx.x, p.nblk);
+    const int tn = L % p.tiles_n, tm = L / p.tiles_n;
+    const int m0 = tm * GB_BM, n0 = tn * GO_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lrow = tid >> 1, lseg = tid & 1;            // loader: row, 16-wide k half
+    const int nk = (p.K + GB_BK - 1) / GB_BK;
+    f32x4 ra[4];
+    bool oka = true;
+
+    auto gload = [&](int kt) {
+        const int k = kt * GB_BK + lseg * 16;
+        int tap = 0, kc = k;
+        if (p.taps == 3) { tap = k / p.Kc; kc = k - tap * p.Kc; }
+        const int m = m0 + lrow;
+        bool ok = (m < p.M) && (k < p.K);
+        long src = m;
+        if (p.taps == 3) {
+            const int pos = m % p.rows_per_seq + tap - 1;
+            ok = ok && (pos >= 0) && (pos < p.rows_per_seq);
+            src = (long)m + tap - 1;
+        }
+        const float* g = p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0);
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                     : "=&v"(ra[0]), "=&v"(ra[1]), "=&v"(ra[2]), "=&v"(ra[3]) : "v"(g) : "memory");
+        oka = ok;
+    };
+    auto wait_all = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 r0 = ra[2 * hh], r1 = ra[2 * hh + 1];
+            if (!oka) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
+            unsigned q[4][NS];
+            gb_split_pair<NS>(r0[0], r0[1], q[0]);
+            gb_split_pair<NS>(r0[2], r0[3], q[1]);
+            gb_split_pair<NS>(r1[0], r1[1], q[2]);
+            gb_split_pair<NS>(r1[2], r1[3], q[3]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
+                *reinterpret_cast<u32x4*>(sA + lrow * RS + s * 64 + lseg * 32 + hh * 16) = v;
+            }
+        }
+    };
+    auto dma_b = [&](int kt) {
+        const char* src = Ws + ((size_t)tn * nk + kt) * Cfg::B_BYTES;
+        for (int off = wave * 1024; off < Cfg::B_BYTES; off += 4 * 1024)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(sB + off), 16, 0, 0);
+    };
+    static_assert(Cfg::B_BYTES % 1024 == 0, "B tile image must be a whole number of 1 KiB DMA pieces");
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt) __builtin_amdgcn_s_barrier();           // everyone finished reading the previous tile
+        dma_b(kt);
+        gload(kt);
+        wait_all();
+        swrite();
+        __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        const char* pa = sA + (wm * 64 + l31) * RS + half * 16;
+        const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u32x4 a[2][NS], b[2][NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a[0][s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
+                a[1][s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
+                b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
+                b[1][s] = *reinterpret_cast<const u32x4*>(pb + 32 * RS + s * 64 + m * 32);
+            }
+            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = (NS == 1 ? 5 : 0); q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = gb_mfma(a[i][NS == 1 ? 0 : PA[q]], b[j][NS == 1 ? 0 : PB[q]], acc[i][j]);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);              // all fragment reads returned before the tile is overwritten
+    }
+
+    const float* bias = p.bias;
+    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
+    float bj[2], sj[2], tj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool okc = col < p.N;
+        bj[j] = (bias && okc) ? bias[col] : 0.f;
+        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
+        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
+    }
+    if (p.rowmax_rows == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                    float v = acc[i][j][r] + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
+                }
+            }
+    } else {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        float mx[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                    float v = acc[i][j][r] + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if (row < p.M) mx[j] = fmaxf(mx[j], v);
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
+        if (half == 0) {
+            red[wm * GO_BN + wn * 64 + l31] = mx[0];
+            red[wm * GO_BN + wn * 64 + 32 + l31] = mx[1];
+        }
+        __syncthreads();
+        if (tid < GO_BN) {
+            const int c = n0 + tid;
+            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GO_BN + tid]);
+        }
+    }
+}
+
+template <int NS>
+int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS>::LDS_BYTES));
+        attr_set = true;
+    }
+    gemm_nt_bf16_occ_kernel<NS><<<p.nblk, GO_THREADS, GOCfg<NS>::LDS_BYTES, st>>>(p, Ws);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
 }  // namespace
 
 // called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
@@ -434,6 +624,12 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     p.rowmax_rows = d->rowmax_rows;
     static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
     p.debug = dbg;
+    if (d->Ws && d->ws_tile_rows == 128) {   // 128-row plane images: three small workgroups per CU
+        p.tiles_n = ceil_div(d->N, GO_BN);
+        p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
+        if (d->precision == EV2H_PREC_BF16X3) return launch_go<3>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_BF16) return launch_go<1>(p, (const char*)d->Ws, (hipStream_t)stream);
+    }
     if (d->Ws) {   // host-packed plane images of W: wide tile, W streamed by LDS-DMA
         p.tiles_n = ceil_div(d->N, GW_BN);
         p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;

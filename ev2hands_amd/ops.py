@@ -76,7 +76,7 @@ def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Te
 
 
 def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=None, post_shift=None, taps=1,
-          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32", presplit: bool = True, w_image=None) -> torch.Tensor:
+          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32", presplit: bool = True, w_image=None, w_tile_rows: int = 128) -> torch.Tensor:
     """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1]."""
     M, ldx = X.shape
     N, ldw = W.shape
@@ -94,10 +94,11 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     d.taps, d.rows_per_seq, d.rowmax_rows = taps, rows_per_seq, rowmax_rows
     d.precision = _lib.PREC[precision]
     keep = None
+    d.ws_tile_rows = w_tile_rows
     if w_image is not None:
         d.Ws = w_image.data_ptr()
-    elif precision != "f32" and N >= 192 and presplit:
-        keep = make_w_image(W, precision)
+    elif precision != "f32" and N >= 96 and presplit:
+        keep = make_w_image(W, precision, w_tile_rows)
         d.Ws = keep.data_ptr()
     L = _lib.lib()
     _lib.check(L.ev2h_init(), "ev2h_init")
@@ -105,10 +106,10 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     return Y
 
 
-def make_w_image(W: torch.Tensor, precision: str) -> torch.Tensor:
-    """bf16 plane images of a dense weight for the wide-tile bf16 GEMM (host-side packing, do it once per weight)."""
+def make_w_image(W: torch.Tensor, precision: str, rows: int = 128) -> torch.Tensor:
+    """bf16 plane images of a dense weight for the bf16 GEMM kernels (host-side packing, do it once per weight)."""
     from .pack import gemm_bf16_w_image
-    return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), {"bf16": 1, "bf16x3": 3}[precision])).to(W.device)
+    return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), {"bf16": 1, "bf16x3": 3}[precision], rows)).to(W.device)
 
 
 def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32") -> torch.Tensor:

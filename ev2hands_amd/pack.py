@@ -110,18 +110,21 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     return img2.reshape(-1), img3.reshape(-1)
 
 
-def gemm_bf16_w_image(W: np.ndarray, ns: int) -> np.ndarray:
-    """bf16 plane images of a dense weight W [N, Ktot] for gemm_nt_bf16_wide_kernel: for every 256-row N tile and
-    every 32-wide K tile one LDS tile image [256 rows][ns*64 + 16 bytes] (planes side by side, 16 B row pad)."""
+GEMM_W_TILE_ROWS = 128     # rows per W image tile (128: occupancy kernel, 256: wide kernel)
+
+
+def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS) -> np.ndarray:
+    """bf16 plane images of a dense weight W [N, Ktot] for the bf16 GEMM kernels: for every `rows`-row N tile and
+    every 32-wide K tile one LDS tile image [rows][ns*64 + 16 bytes] (planes side by side, 16 B row pad)."""
     N, K = W.shape
-    tn, nk = _up(N, 256) // 256, _up(K, 32) // 32
-    Wp = _pad(W, tn * 256, nk * 32)
+    tn, nk = _up(N, rows) // rows, _up(K, 32) // 32
+    Wp = _pad(W, tn * rows, nk * 32)
     planes = split_bf16_planes(Wp, ns)
     rs = ns * 64 + 16
-    img = np.zeros((tn, nk, 256, rs), dtype=np.uint8)
+    img = np.zeros((tn, nk, rows, rs), dtype=np.uint8)
     for s_ in range(ns):
-        blk = planes[s_].reshape(tn, 256, nk, 32).transpose(0, 2, 1, 3)          # [tn, nk, 256, 32] uint16
-        img[:, :, :, s_ * 64:(s_ + 1) * 64] = np.ascontiguousarray(blk).view(np.uint8).reshape(tn, nk, 256, 64)
+        blk = planes[s_].reshape(tn, rows, nk, 32).transpose(0, 2, 1, 3)         # [tn, nk, rows, 32] uint16
+        img[:, :, :, s_ * 64:(s_ + 1) * 64] = np.ascontiguousarray(blk).view(np.uint8).reshape(tn, nk, rows, 64)
     return img.reshape(-1)
 
 
@@ -204,8 +207,9 @@ class PackedWeights:
         d.post_scale = self._dev(name + ".ps", post_scale) if post_scale is not None else None
         d.post_shift = self._dev(name + ".pt", post_shift) if post_shift is not None else None
         d.O, d.K, d.ldw = O, (ldw if K is None else K), ldw
-        if self.ns and O >= 192:      # big layers use the wide-tile kernel with pre-split W
+        if self.ns and O >= 96:       # all but the tiny heads: pre-split W images, streamed by LDS-DMA
             d.Ws = self._dev_bytes(name + ".Ws", gemm_bf16_w_image(_pad(W, O, ldw), self.ns))
+            d.ws_tile_rows = GEMM_W_TILE_ROWS
 
     def _group_all(self, arr, sd, prefix, nlayers):
         """sample_and_group_all concatenates [xyz(3), features(512)] (pointnet2_utils.py:155); our

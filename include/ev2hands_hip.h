@@ -93,8 +93,9 @@ typedef struct ev2h_gemm_desc {
     int rows_per_seq;            /* rows per window when taps == 3                                      */
     int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
     int precision;               /* EV2H_PREC_*; BF16 / BF16X3 need K % 8 == 0 (operands are split on the fly) */
-    const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in 256-row x 32-k LDS tiles
-                                    (ev2hands_amd/pack.py: gemm_bf16_w_image); selects the wide-tile kernel */
+    const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in (ws_tile_rows)-row x 32-k LDS
+                                    tiles (ev2hands_amd/pack.py: gemm_bf16_w_image); NULL = split W on the fly  */
+    int ws_tile_rows;            /* 128 (three 4-wave workgroups per CU) or 256 (one 8-wave workgroup)           */
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 
@@ -171,6 +172,7 @@ typedef struct ev2h_dense {       /* one folded Conv/Linear: W [O][ldw], b [O], 
     const float* W; const float* b; const float* post_scale; const float* post_shift;
     int O, K, ldw;
     const void* Ws;               /* bf16 plane images of W (NULL: split on the fly / F32)              */
+    int ws_tile_rows;             /* rows per image tile: 128 or 256                                    */
 } ev2h_dense;
 
 typedef struct ev2h_weights {

@@ -110,9 +110,10 @@ GEMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("bf16x3", 3e-6), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol,wrows", [("f32", 2e-6, 128), ("bf16x3", 3e-6, 128), ("bf16x3", 3e-6, 256), ("bf16", 2e-2, 128),
+                                                 ("bf16", 2e-2, 256)])
 @pytest.mark.parametrize("M,N,K,relu,post,taps,rowmax,group", GEMM_CASES)
-def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol):
+def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
     _need_gpu()
     from ev2hands_amd import ops
     X = torch.from_numpy(synth.hash_normal("X", (M, K), 2)).float()
@@ -139,7 +140,7 @@ def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol):
     if rowmax:
         ref = ref.view(M // rowmax, rowmax, N).max(1)[0]
     got = ops.dense(X.cuda(), W.cuda(), b.cuda() if group else b[0].cuda(), relu, ps.cuda() if post else None,
-                    pt.cuda() if post else None, taps, seq, rowmax, group, K, precision)
+                    pt.cuda() if post else None, taps, seq, rowmax, group, K, precision, w_tile_rows=wrows)
     assert got.shape == ref.shape
     err = rel(got, ref)
     print(f"gemm M={M} N={N} K={K} taps={taps} {precision}: rel err {err:.2e}")

@@ -57,7 +57,7 @@ def bench_sa(B=256, precision="f32"):
         print(f"[{precision}] sa<{C1},{C2},{C3}> K={K} S={S} {tag:10s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}% of fp32 MFMA peak)")
 
 
-def bench_gemm(B=256, N=2048, precision="f32"):
+def bench_gemm(B=256, N=2048, precision="f32", rows=128):
     R = B * N
     for (M, Nn, K, taps, tag) in [(R, 512, 256, 3, "qconv0"), (R, 256, 256, 3, "qconv4"), (R, 256, 128, 1, "fp1.2"), (R, 128, 128, 1, "fp1.0"),
                                   (R, 256, 256, 1, "cls0"), (R, 4, 256, 1, "cls4"), (R, 160, 8, 1, "P1a"), (R, 256, 8, 1, "P1m"),
@@ -66,10 +66,11 @@ def bench_gemm(B=256, N=2048, precision="f32"):
         X = torch.randn(M, K, device="cuda")
         W = torch.randn(Nn, K * taps, device="cuda") * (K * taps) ** -0.5
         b = torch.randn(Nn, device="cuda")
-        wi = ops.make_w_image(W, precision) if (precision != "f32" and Nn >= 192) else None
-        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K, precision=precision, w_image=wi))
+        wi = ops.make_w_image(W, precision, rows) if (precision != "f32" and Nn >= 96) else None
+        ms = timeit(lambda: ops.dense(X, W, b, True, taps=taps, rows_per_seq=N if taps == 3 else 0, K=K, precision=precision, w_image=wi,
+                                      w_tile_rows=rows))
         flop = 2.0 * M * Nn * K * taps
-        print(f"[{precision}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
+        print(f"[{precision}/{rows}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
 
 
 if __name__ == "__main__":
@@ -82,5 +83,6 @@ if __name__ == "__main__":
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemmb", "all"):
-        bench_gemm(precision="bf16x3")
-        bench_gemm(precision="bf16")
+        bench_gemm(precision="bf16x3", rows=128)
+        bench_gemm(precision="bf16x3", rows=256)
+        bench_gemm(precision="bf16", rows=128)
