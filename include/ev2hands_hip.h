@@ -151,6 +151,18 @@ typedef struct ev2h_mano_consts {
 int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, float* joints,
               ev2h_stream_t stream);
 
+/* ---- event window -> [5, N] tensor (next row 8f-1; dataset/evaluation_stream.py:187-225, ev2hands_r.py:108-159) ---- */
+/* Per-pixel accumulation + np.nonzero-order compaction of B ragged windows.  events: device [E_total][4] float64 rows
+ * (x, y, t_ms, polarity) in stream order, exactly the array the reference builds; offsets: device [B+1] row offsets
+ * (<= 32768 events per window).  uniq [B][cap][8] float32 records (x, y, t_avg, pos_cnt, neg_cnt, 0, 0, 0) of the pixels
+ * hit, in row-major pixel order; uniq_count [B] (-1 if a window is too large).  Bit-identical to np.add.at / np.nonzero. */
+int ev2h_event_window_build(const double* events, const int32_t* offsets, int B, int width, int height, int cap,
+                            int32_t* uniq_count, float* uniq, ev2h_stream_t stream);
+/* Resampling with replacement + pc_normalize: sample_idx [B][N] int32 (the reference draws them with
+ * np.random.choice(M, N) on the host) -> out_cm [B][5][N] float32 = (x, y, t, pos_cnt, neg_cnt), the hot path's input. */
+int ev2h_event_window_sample(const float* uniq, const int32_t* uniq_count, int cap, const int32_t* sample_idx, int B, int N,
+                             int width, int height, float* out_cm, ev2h_stream_t stream);
+
 /* ---- whole path -------------------------------------------------------------------------------------- */
 typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;

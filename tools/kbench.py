@@ -73,6 +73,40 @@ def bench_gemm(B=256, N=2048, precision="f32", rows=128):
         print(f"[{precision}/{rows}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
 
 
+def bench_events(B=256, n_ev=2500):
+    import time
+    import numpy as np
+    from ev2hands_amd.events import EventWindowBuilder
+    from oracle import event_window_oracle as EW
+    wins = []
+    for k in range(8):
+        s_ = EW.synth_event_stream(n_ev, 50 + k).astype(np.float64)
+        s_[:, 2] *= 1e-3
+        wins.append(s_)
+    wins = (wins * (B // 8))[:B]
+    bld = EventWindowBuilder("cuda:0")
+    table, counts = bld.accumulate(wins)
+    idx = np.stack([np.random.RandomState(i).randint(0, int(c), 2048) for i, c in enumerate(counts.cpu().numpy())])
+    # device-only timing: inputs already resident
+    import ctypes as C
+    from ev2hands_amd import _lib
+    offs = np.zeros(B + 1, dtype=np.int32); offs[1:] = np.cumsum([w.shape[0] for w in wins])
+    ev = torch.from_numpy(np.concatenate(wins, 0)).cuda(); off = torch.from_numpy(offs).cuda()
+    idt = torch.from_numpy(idx.astype(np.int32)).cuda()
+    out = torch.empty(B, 5, 2048, device="cuda")
+    L = _lib.lib()
+    def fn():
+        _lib.check(L.ev2h_event_window_build(ev.data_ptr(), off.data_ptr(), B, 346, 260, bld.cap, counts.data_ptr(), table.data_ptr(), _lib.stream_handle()), "b")
+        _lib.check(L.ev2h_event_window_sample(table.data_ptr(), counts.data_ptr(), bld.cap, idt.data_ptr(), B, 2048, 346, 260, out.data_ptr(), _lib.stream_handle()), "s")
+    ms = timeit(fn, iters=10)
+    t0 = time.time()
+    for w, i in zip(wins[:32], idx[:32]):
+        EW.build_window(w, i)
+    cpu = 32 / (time.time() - t0)
+    print(f"event-window builder: B={B} windows x {n_ev} events -> [B,5,2048]: {ms:.3f} ms  ({B / ms * 1e3:.0f} windows/s on the GPU, "
+          f"oracle (numpy, 1 thread) {cpu:.0f} windows/s)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("sa", "all"):
@@ -80,6 +114,8 @@ if __name__ == "__main__":
     if what in ("sab", "all"):
         bench_sa(precision="bf16x3")
         bench_sa(precision="bf16")
+    if what in ("events", "all"):
+        bench_events()
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemmb", "all"):
