@@ -163,6 +163,15 @@ int ev2h_event_window_build(const double* events, const int32_t* offsets, int B,
 int ev2h_event_window_sample(const float* uniq, const int32_t* uniq_count, int cap, const int32_t* sample_idx, int B, int N,
                              int width, int height, float* out_cm, ev2h_stream_t stream);
 
+/* ---- per-frame joint metrics (next row 8f-3; evaluate.py:185-234, evaluate_ev2hands_r.py:35-89) ------------------------ */
+/* j3d_left / j3d_right [B][21][3] float32 metres (the forward's outputs); j3d_gts [B][G][2][21][3] float64 metres (G ground-truth
+ * candidates per frame).  For the candidate with the best rounded right-root-relative AUC (first on ties): pck [B][3][num_steps+1]
+ * (absolute, relative, right-root-relative), auc [B][3] (trapezoid / n, NOT yet rounded), mpjpe [B] (mm), root_distance [B] (mm),
+ * best [B]. */
+int ev2h_joint_metrics(const float* j3d_left, const float* j3d_right, const double* j3d_gts, int B, int G, int num_steps,
+                       double dist_max_mm, float* pck, double* auc, double* mpjpe, double* root_distance, int32_t* best,
+                       ev2h_stream_t stream);
+
 /* ---- whole path -------------------------------------------------------------------------------------- */
 typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;

@@ -12,7 +12,7 @@ import torch
 from ev2hands_amd import synth
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith("events_"))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_")))
 TOL = 1e-4
 
 
