@@ -88,6 +88,9 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported before the library: both depend on libamdhip64 and the process must end up with ONE HIP
+    # runtime (torch's bundled copy).  Loading ours first pulls /opt/rocm's copy and leaves it without a device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise Ev2hError(f"{LIB_PATH} is missing: build the HIP library first "
                         f"(python -m ev2hands_amd.build). There is no CPU fallback.")

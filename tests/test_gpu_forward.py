@@ -228,3 +228,36 @@ def test_bf16_mode_reports_mpjpe_and_argmax_agreement():
     agree = float((outs["f32"]["logits"].argmax(1) == outs["bf16"]["logits"].argmax(1)).float().mean())
     print(f"bf16 vs fp32: root-relative MPJPE {mpjpe_mm:.4f} mm over 42 joints, argmax agreement {agree * 100:.3f} %")
     assert mpjpe_mm < 5.0 and agree > 0.97
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_full_size_batch_properties(precision):
+    """BASELINE.json config 2 size (B=64, N=2048, C=4), too slow for the CPU oracle: size-independent properties instead --
+    permuting the windows of a batch permutes every output bit-exactly (windows are independent, weights shared), and the
+    two fp32-class arithmetic modes agree with each other within the parity tolerance."""
+    _need_gpu()
+    B, C, N, seed = 64, 4, 2048, 9
+    net, sd, assets = make_net(C, seed, precision=precision)
+    xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    perm = torch.from_numpy(np.argsort(synth.hash_uniform("perm", (B,), seed)))
+    net.net.fps_init = inits
+    with torch.no_grad():
+        a = net(xyz)
+        a = {"l": a["class_logits"].clone(), "v": a["left"]["vertices"].clone(), "j": a["right"]["j3d"].clone(),
+             "p": a["right"]["betas"].clone()}
+        net.net.fps_init = [t[perm] for t in inits]
+        b = net(xyz[perm.cuda()].contiguous())
+    pc = perm.cuda()
+    assert torch.equal(a["l"][pc], b["class_logits"]) and torch.equal(a["v"][pc], b["left"]["vertices"])
+    assert torch.equal(a["j"][pc], b["right"]["j3d"]) and torch.equal(a["p"][pc], b["right"]["betas"])
+    assert torch.isfinite(a["l"]).all() and torch.isfinite(a["v"]).all()
+    if precision == "bf16x3":
+        net32, _, _ = make_net(C, seed, precision="f32")
+        net32.net.fps_init = inits
+        with torch.no_grad():
+            r = net32(xyz)
+        assert rel(a["l"], r["class_logits"]) < TOL and rel(a["v"], r["left"]["vertices"]) < TOL
+        agree = float((a["l"].argmax(1) == r["class_logits"].argmax(1)).float().mean())
+        print(f"bf16x3 vs f32 at B=64: logits rel {rel(a['l'], r['class_logits']):.2e}, argmax agreement {agree * 100:.4f} %")
+        assert agree == 1.0
