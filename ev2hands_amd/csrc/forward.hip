@@ -3,6 +3,7 @@
 // no host synchronisation, no device->host copies inside (hipGraph-capturable).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -71,6 +72,29 @@ static inline void prof_begin(const char* tag, ev2h_stream_t st) {
 }
 static inline void prof_end(const char* tag, ev2h_stream_t st) {
     if (prof_hit(tag)) { (void)hipEventRecord(g_prof.stop[g_prof.calls % g_prof.n], (hipStream_t)st); ++g_prof.calls; }
+}
+
+// ---------------------------------------------------------------------------------------- side stream
+// The two MANO regressors are independent after the attention block, and their ball queries depend only on the
+// sampled centroids.  They are forked onto one library-owned side stream (fork/join with events, hipGraph-capturable),
+// so the small kernels of one hand (ball query, table GEMM, head GEMMs, MANO) overlap the MFMA-heavy kernels of the
+// other and fill their tails.  Measured gain at B=256: 0.6 % (both hands' big kernels fill the chip on their own), so the
+// fork is OPT-IN (EV2H_TWO_STREAMS=1); it also keeps the per-kernel event timing of bench.py free of overlap.
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+static int g_side_state = 0;   // 0 = not tried, 1 = ready, -1 = disabled
+
+static bool side_ready() {
+    if (g_side_state == 0) {
+        const char* e = getenv("EV2H_TWO_STREAMS");
+        g_side_state = -1;
+        if ((e && atoi(e) != 0) && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess) {
+            bool ok = true;
+            for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) g_side_state = 1;
+        }
+    }
+    return g_side_state == 1;
 }
 
 // ---------------------------------------------------------------------------------------- small kernels
@@ -293,6 +317,22 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         float* ctr[3] = {ws.f("ctr1"), ws.f("ctrmL"), ws.f("ctrmR")};
         RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
     }
+    // fork 1: both hands' ball queries only need the raw cloud and their centroids
+    const bool fork = side_ready();
+    ev2h_stream_t sd = fork ? (ev2h_stream_t)g_side : st;
+    if (fork) {
+        EV2H_CHECK_HIP(hipEventRecord(g_ev[0], (hipStream_t)st));
+        EV2H_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev[0], 0));
+    }
+    for (int h = 0; h < 2; ++h) {
+        const ev2h_sa_module& m = w->mano_sa1[h];
+        const char* const* nm = kHandNames[h];
+        float rad[2]; int ns[2];
+        int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
+        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
+        RUN(ev2h_ball_query(ws.f("pts4"), ws.f(nm[2]), B, N, 128, 2, rad, ns, gi, ws.i(nm[5]), sd));
+    }
+    if (fork) EV2H_CHECK_HIP(hipEventRecord(g_ev[1], g_side));
     // ---- enc.sa1 (TEHNet.py:179)
     {
         const ev2h_sa_module& m = w->sa1;
@@ -345,23 +385,30 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     // ---- attention (TEHNet.py:13-27)
     RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
     RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), st));
-    // ---- MANO regressors (TEHNet.py:194-195, 68-112)
+    // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
+    if (fork) {
+        EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, g_ev[1], 0));       // ball queries done
+        EV2H_CHECK_HIP(hipEventRecord(g_ev[2], (hipStream_t)st));              // attention output (hf8) ready
+        EV2H_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev[2], 0));
+    }
     for (int h = 0; h < 2; ++h) {
         const ev2h_sa_module& m = w->mano_sa1[h];
         const char* const* nm = kHandNames[h];
-        float rad[2]; int ns[2];
+        ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
-        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
-        RUN(ev2h_ball_query(ws.f("pts4"), ws.f(nm[2]), B, N, 128, 2, rad, ns, gi, ws.i(nm[5]), st));
-        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, st));
-        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
+        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh));
+        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)sh>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
                                                                                    ws.f(nm[6]), 520, 512);
         EV2H_CHECK_LAUNCH();
-        RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, st));
-        RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, st, nullptr, 0, 0, 1, 0, 128));
-        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, st));
-        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, st));
-        RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], st));
+        RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh));
+        RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, nullptr, 0, 0, 1, 0, 128));
+        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh));
+        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh));
+        RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
+    }
+    if (fork) {                                                                // join
+        EV2H_CHECK_HIP(hipEventRecord(g_ev[3], g_side));
+        EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, g_ev[3], 0));
     }
     return EV2H_OK;
 }
