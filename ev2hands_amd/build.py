@@ -26,7 +26,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -ffp-contract=off: hipcc would otherwise fuse a*b+c into fma and change the roundings the discrete
     # selections (FPS argmax, radius test, 3-NN) are sensitive to; every intended fma is an explicit fmaf.
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I" + CSRC, "-I" + INCLUDE]
+    # -fno-slp-vectorize: packed fp32 VALU ops (v_pk_add_f32 / v_pk_fma_f32) that the SLP vectoriser forms out of adjacent
+    # scalar operations run slower than the scalar pairs next to MFMAs on gfx950 (measured: SA kernels 5-7 % faster).
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+           "-I" + CSRC, "-I" + INCLUDE]
+    cmd += os.environ.get("EV2H_BUILD_DEFS", "").split()      # e.g. -DEV2H_SAB_TIMELINE (tools/sa_timeline.py)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)

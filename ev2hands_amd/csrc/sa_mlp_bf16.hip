@@ -30,6 +30,14 @@ struct SaBP {
     int nblk;
 };
 
+// EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
+// wave 0 of one workgroup records s_memtime at the phase boundaries of its second strip (costs ~10 % of the kernel time)
+#ifdef EV2H_SAB_TIMELINE
+__device__ long long g_sab_timeline[256];
+#define STAMP(i) do { if (dbgw && strip == dbg_strip) g_sab_timeline[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 constexpr int SAB_WAVES = 8;
 constexpr int SAB_THREADS = SAB_WAVES * 64;
 
@@ -72,6 +80,31 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&o)[NS]
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float relu_bits(float x) {     // max(x, 0) as one integer max: no canonicalisation op, -0 -> +0
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+__device__ __forceinline__ unsigned pack_hi16(float x1, float x0) {     // bf16 (truncated) of x1 : x0, one v_perm_b32
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+// same planes as split_pair with v_perm packs; the residual subtracts stay scalar (packed fp32 VALU ops are slower than
+// two plain ones on gfx950 next to MFMAs, which is also why the build passes -fno-slp-vectorize)
+template <int NS>
+__device__ __forceinline__ void split_pair_v(f32x2 x, unsigned (&o)[NS]) {
+    if constexpr (NS == 1) {
+        split_pair<1>(x[0], x[1], o);
+    } else {
+        o[0] = pack_hi16(x[1], x[0]);
+        const float r0 = x[0] - __uint_as_float(__float_as_uint(x[0]) & 0xffff0000u);
+        const float r1 = x[1] - __uint_as_float(__float_as_uint(x[1]) & 0xffff0000u);
+        o[1] = pack_hi16(r1, r0);
+        const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        o[2] = pack_hi16(q1, q0);
+    }
+}
+
 // acc += sum over the kept plane products of A-plane x B-plane (smallest terms first)
 template <int NS>
 __device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16 acc) {
@@ -94,7 +127,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wt0 = smem;
     char* wt1 = smem + Cfg::TILE;
-    float4* sW1x = reinterpret_cast<float4*>(smem + 2 * Cfg::TILE);
+    f32x4* sW1xT = reinterpret_cast<f32x4*>(smem + 2 * Cfg::TILE);     // per 4 channels: x[4], y[4], z[4]
     float* sb2 = reinterpret_cast<float*>(smem + 2 * Cfg::TILE + C1 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,7 +140,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int gg = valid ? g : ngroups - 1;
     const int b = gg / p.S;
 
-    for (int i = tid; i < C1; i += SAB_THREADS) sW1x[i] = p.W1x[i];
+    for (int i = tid; i < C1; i += SAB_THREADS) {
+        const float4 w = p.W1x[i];
+        float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
+        d[0] = w.x; d[4] = w.y; d[8] = w.z;
+    }
     for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i];
 
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
@@ -134,7 +171,12 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef EV2H_SAB_TIMELINE
+    const bool dbgw = (blockIdx.x == 300 && tid == 0);
+    const int dbg_strip = nstrips > 1 ? 1 : 0;
+#endif
     for (int strip = 0; strip < nstrips; ++strip) {
+        STAMP(0);
         const int idx = gi[strip * 32 + l31];
         const float4 q = p.pts4[(size_t)b * p.Npts + idx];
         const float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
@@ -144,14 +186,24 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
 
         // ---------------- layer 2 (contraction-chunk outer): h2[t] = D2[channel 32t + mfma_row(r,half)][neighbour]
+        // (the accumulators start at the b2 bias: D rows 4j..4j+3 of a lane are 4 consecutive channels)
         f32x16 h2[T2];
 #pragma unroll
         for (int t = 0; t < T2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h2[t][r] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 32 * t + 8 * j + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h2[t][4 * j + e] = bv[e];
+            }
 
+#ifdef EV2H_SAB_TIMELINE
+        if (dbgw && strip == dbg_strip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(1);
 #pragma unroll 1
         for (int c = 0; c < NC1; ++c) {
+            STAMP(2 + 4 * c);
             char* cur = buf ? wt1 : wt0;
             char* nxt = buf ? wt0 : wt1;
             if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt);
@@ -163,15 +215,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             u32x4 bp[2][NS];
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
-                float hv[4];
+                const f32x4* wp = sW1xT + (8 * c + 4 * half + j4) * 3;
+                const f32x4 wx = wp[0], wy = wp[1], wz = wp[2];
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float4 w = sW1x[32 * c + 16 * half + j4 * 4 + e];
-                    hv[e] = fmaxf(__fmaf_rn(w.z, dz, __fmaf_rn(w.y, dy, __fmaf_rn(w.x, dx, raw[j4][e]))), 0.f);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
                 unsigned lo[NS], hi[NS];
-                split_pair<NS>(hv[0], hv[1], lo);
-                split_pair<NS>(hv[2], hv[3], hi);
+                split_pair_v<NS>(f32x2{relu_bits(v[0]), relu_bits(v[1])}, lo);
+                split_pair_v<NS>(f32x2{relu_bits(v[2]), relu_bits(v[3])}, hi);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 0] = lo[s];
@@ -182,48 +233,67 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
             }
+            STAMP(3 + 4 * c);
             const char* pa = cur + l31 * RS2 + (16 * half) * 2;
+            // the 2*T2 (k-block m, tile t) groups are taken two at a time and their MFMAs alternate between the two tiles'
+            // accumulators: anything issued between two MFMAs on the SAME accumulator (here the next fragment reads) costs
+            // ~43 cycles, between MFMAs on different accumulators ~6 (MI355X_MICROARCH.md, latency table)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int pr = 0; pr < T2; ++pr) {
+                const int m0 = (2 * pr) / T2, t0 = (2 * pr) % T2, m1 = (2 * pr + 1) / T2, t1 = (2 * pr + 1) % T2;
+                u32x4 a0[NS], a1[NS];
 #pragma unroll
-                for (int t = 0; t < T2; ++t) {
-                    u32x4 a[NS];
+                for (int s = 0; s < NS; ++s) {
+                    a0[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t0 * RS2 + s * 64 + m0 * 16);
+                    a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t1 * RS2 + s * 64 + m1 * 16);
+                }
+                if constexpr (NS == 1) {
+                    h2[t0] = mfma_bf16(a0[0], bp[m0][0], h2[t0]);
+                    h2[t1] = mfma_bf16(a1[0], bp[m1][0], h2[t1]);
+                } else {
+                    constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};   // smallest terms first
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) a[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t * RS2 + s * 64 + m * 16);
-                    h2[t] = mfma_split<NS>(a, bp[m], h2[t]);
+                    for (int j = 0; j < 6; ++j) {
+                        h2[t0] = mfma_bf16(a0[ia[j]], bp[m0][ib[j]], h2[t0]);
+                        h2[t1] = mfma_bf16(a1[ia[j]], bp[m1][ib[j]], h2[t1]);
+                    }
                 }
             }
+            STAMP(4 + 4 * c);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued above has landed
             __syncthreads();
+            STAMP(5 + 4 * c);
             buf ^= 1;
         }
 
-        // bias + ReLU in fp32, then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
+        STAMP(38);
+        // ReLU in fp32 (the bias is already in), then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
         u32x4 h2p[NS][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
 #pragma unroll
         for (int t = 0; t < T2; ++t) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float v0 = fmaxf(h2[t][2 * k] + sb2[32 * t + mfma_row(2 * k, half)], 0.f);
-                const float v1 = fmaxf(h2[t][2 * k + 1] + sb2[32 * t + mfma_row(2 * k + 1, half)], 0.f);
                 unsigned o[NS];
-                split_pair<NS>(v0, v1, o);
+                split_pair_v<NS>(f32x2{relu_bits(h2[t][2 * k]), relu_bits(h2[t][2 * k + 1])}, o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
         }
+        STAMP(39);
 
         // ---------------- layer 3 + max: D3[neighbour][channel] = H2 (A, registers) x W3 tile (B, LDS, permuted k order)
 #pragma unroll 1
         for (int u = 0; u < T3; ++u) {
+            STAMP(40 + 4 * u);
             char* cur = buf ? wt1 : wt0;
             char* nxt = buf ? wt0 : wt1;
             const bool more_w3 = (u + 1 < T3);
             const bool more = more_w3 || (strip + 1 < nstrips);
             if (more_w3) dma_w3(u + 1, nxt); else if (more) dma_w2(0, nxt);
-            f32x16 acc;
+            // two accumulators take alternate plane products (see layer 2); their sum is the tile
+            f32x16 acc, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
             const char* pb = cur + l31 * RS3 + (8 * half) * 2;
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -238,27 +308,34 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         }
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
                         if constexpr (NS == 1) {
-                            acc = mfma_bf16(a[0], w[0], acc);
+                            if (m == 0) acc = mfma_bf16(a[0], w[0], acc); else acc1 = mfma_bf16(a[0], w[0], acc1);
                         } else {
                             acc = mfma_bf16(a[0], w[2], acc);
-                            acc = mfma_bf16(a[2], w[0], acc);
+                            acc1 = mfma_bf16(a[2], w[0], acc1);
                             acc = mfma_bf16(a[1], w[1], acc);
-                            acc = mfma_bf16(a[0], w[1], acc);
+                            acc1 = mfma_bf16(a[0], w[1], acc1);
                             acc = mfma_bf16(a[1], w[0], acc);
-                            acc = mfma_bf16(a[0], w[0], acc);
+                            acc1 = mfma_bf16(a[0], w[0], acc1);
                         }
                     }
                 }
             }
-            float mx = acc[0];
+            STAMP(41 + 4 * u);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, acc[15]);
 #pragma unroll
             for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
+            STAMP(42 + 4 * u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            STAMP(43 + 4 * u);
             buf ^= 1;
         }
+        STAMP(37);
     }
 
 #pragma unroll
@@ -295,6 +372,11 @@ int dispatch_sab(const SaBP& p, int c1, int c2, int c3, hipStream_t st) {
 
 }  // namespace
 
+#ifdef EV2H_SAB_TIMELINE
+extern "C" int ev2h_sab_timeline_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sab_timeline), sizeof(long long) * 256);
+}
+#endif
 // called by ev2h_sa_mlp_max when d->precision != EV2H_PREC_F32
 int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d->W2s && d->W3s);

@@ -36,6 +36,9 @@ def bench_sa(B=256, precision="f32"):
         b2 = torch.randn(up(C2, 32), device=d)
         W3 = torch.randn(C3, up(C2, 8), device=d) * C2 ** -0.5
         b3 = torch.randn(C3, device=d)
+        if os.environ.get("KBENCH_ZERO"):      # same instruction stream on all-zero data: separates power (DVFS) from cycles
+            for x in (P1, pts4, ctr4, W1x, W2, b2, W3, b3):
+                x.zero_()
         if precision == "f32":
             fn = lambda: ops.sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2)
         else:
