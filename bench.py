@@ -30,9 +30,10 @@ from ev2hands_amd import _lib, dist as evdist, synth  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # same table, dense bf16 matrix peak
 # plane products executed per algorithmic multiply-add in each arithmetic mode
-PRODUCTS = {"f32": 1, "bf16x3": 6, "bf16": 1}
-DTYPE = {"f32": "f32",
+PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1}
+DTYPE = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
          "bf16x3": "f32 (each f32 operand split exactly into 3 bf16 planes, 6 plane products per MAC on the bf16 MFMA, f32 accumulate)",
+         "f16x2": "f32 (each f32 operand split into 2 fp16 planes, 3 plane products per MAC on the f16 MFMA, f32 accumulate)",
          "bf16": "bf16 (f32 accumulate)"}
 # algorithmic work of the profiled kernel per window: layers 2+3 of mano.sa1 branch 1
 # (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
@@ -49,9 +50,10 @@ def parse():
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--cloud", default="E", choices=["U", "E"])
-    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "bf16x3"), choices=["f32", "bf16x3", "bf16"],
-                    help="arithmetic of the MFMA contractions: bf16x3 = fp32-class 3-plane split (default, passes the "
-                         "1e-4 / exact-argmax parity bar), f32 = v_mfma_f32_32x32x2_f32, bf16 = reduced precision (config 3)")
+    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f16x2"), choices=["f32", "bf16x3", "f16x2", "bf16"],
+                    help="arithmetic of the MFMA contractions: f16x2 = fp32-class 2-plane fp16 split (default), bf16x3 = fp32-class "
+                         "3-plane bf16 split (full fp32 range) -- both pass the 1e-4 / exact-argmax parity bar -- "
+                         "f32 = v_mfma_f32_32x32x2_f32, bf16 = reduced precision (BASELINE.json config 3)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra exact-f32-MFMA timing leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -190,17 +192,20 @@ def main():
     dt = timed(a.steps)
     L.ev2h_profile_set(None, None, None, 0)
 
-    # transparency leg: the same workload with exact f32 MFMA arithmetic (not part of `value`)
-    f32_leg = None
-    if a.precision != "f32" and not a.no_f32_leg:
-        net.net.precision = "f32"
-        for _ in range(max(1, a.warmup)):
-            step()
-        k = max(2, a.steps // 2)
-        dtf = timed(k)
-        f32_leg = {"value": round(gB * k / dtf, 2), "ms_per_step": round(dtf / k * 1e3, 3), "steps": k,
-                   "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    # transparency legs: the same workload in the other arithmetic modes (not part of `value`)
+    legs = {}
+    if not a.no_f32_leg:
+        for prec in ("f32", "bf16x3", "f16x2", "bf16"):
+            if prec == a.precision:
+                continue
+            net.net.precision = prec
+            for _ in range(max(1, a.warmup)):
+                step()
+            k = max(2, a.steps // 2)
+            dtf = timed(k)
+            legs[prec] = {"value": round(gB * k / dtf, 2), "ms_per_step": round(dtf / k * 1e3, 3), "steps": k, "dtype": DTYPE[prec]}
         net.net.precision = a.precision
+    f32_leg = legs.pop("f32", None)
 
     if rank == 0:
         kms = ev.elapsed_ms(a.steps)
@@ -230,6 +235,8 @@ def main():
         }
         if f32_leg:
             res["f32_mfma_leg"] = f32_leg
+        if legs:
+            res["other_modes"] = legs
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         print(json.dumps(res), flush=True)

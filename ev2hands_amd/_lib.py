@@ -54,7 +54,7 @@ class Weights(C.Structure):
                 ("mano_sa2", (Dense * 2) * 2),
                 ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci)]
 
-PREC = {"f32": 0, "bf16": 1, "bf16x3": 3}
+PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
 
 
 class ManoConsts(C.Structure):

@@ -8,13 +8,11 @@
 // next K tile, two LDS buffers, one barrier per K tile.
 #include <cstdlib>
 
-#include "common.hpp"
+#include "planes.hpp"
 #include "ev2hands_hip.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_BM = 128, GB_BN = 128, GB_BK = 32, GB_THREADS = 512;
 
@@ -38,26 +36,6 @@ struct GBCfg {
     static constexpr int OPER = GB_BM * RS;                 // one operand tile
     static constexpr int LDS_BYTES = 4 * OPER;              // 2 buffers x (A, B)
 };
-
-__device__ __forceinline__ f32x16 gb_mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <int NS>
-__device__ __forceinline__ void gb_split_pair(float x0, float x1, unsigned (&o)[NS]) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    if constexpr (NS == 1) {
-        const unsigned r0 = u0 + 0x7fffu + ((u0 >> 16) & 1u), r1 = u1 + 0x7fffu + ((u1 >> 16) & 1u);
-        o[0] = (r1 & 0xffff0000u) | (r0 >> 16);
-    } else {
-        o[0] = (u1 & 0xffff0000u) | (u0 >> 16);
-        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-        o[1] = (v1 & 0xffff0000u) | (v0 >> 16);
-        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-        o[2] = (__float_as_uint(s1) & 0xffff0000u) | (__float_as_uint(s0) >> 16);
-    }
-}
 
 template <int NS>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
@@ -111,10 +89,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
     };
     auto swrite_one = [&](char* dst, const f32x4 (&r)[2]) {
         unsigned q[4][NS];
-        gb_split_pair<NS>(r[0][0], r[0][1], q[0]);
-        gb_split_pair<NS>(r[0][2], r[0][3], q[1]);
-        gb_split_pair<NS>(r[1][0], r[1][1], q[2]);
-        gb_split_pair<NS>(r[1][2], r[1][3], q[3]);
+        split_planes<NS>(r[0][0], r[0][1], q[0]);
+        split_planes<NS>(r[0][2], r[0][3], q[1]);
+        split_planes<NS>(r[1][0], r[1][1], q[2]);
+        split_planes<NS>(r[1][2], r[1][3], q[3]);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
@@ -148,16 +126,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
                 a0[s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
                 a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
             }
-            if constexpr (NS == 1) {
-                acc[0] = gb_mfma(a0[0], b[0], acc[0]);
-                acc[1] = gb_mfma(a1[0], b[0], acc[1]);
-            } else {
-                acc[0] = gb_mfma(a0[0], b[2], acc[0]); acc[1] = gb_mfma(a1[0], b[2], acc[1]);
-                acc[0] = gb_mfma(a0[2], b[0], acc[0]); acc[1] = gb_mfma(a1[2], b[0], acc[1]);
-                acc[0] = gb_mfma(a0[1], b[1], acc[0]); acc[1] = gb_mfma(a1[1], b[1], acc[1]);
-                acc[0] = gb_mfma(a0[0], b[1], acc[0]); acc[1] = gb_mfma(a1[0], b[1], acc[1]);
-                acc[0] = gb_mfma(a0[1], b[0], acc[0]); acc[1] = gb_mfma(a1[1], b[0], acc[1]);
-                acc[0] = gb_mfma(a0[0], b[0], acc[0]); acc[1] = gb_mfma(a1[0], b[0], acc[1]);
+#pragma unroll
+            for (int q = 0; q < Planes<NS>::NPROD; ++q) {
+                acc[0] = mfma_planes<NS>(a0[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[0]);
+                acc[1] = mfma_planes<NS>(a1[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[1]);
             }
         }
         if (kt + 1 < nk) {
@@ -282,10 +254,10 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         f32x4 r[2] = {ra[0], ra[1]};
         if (!oka) { r[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[1] = r[0]; }
         unsigned q[4][NS];
-        gb_split_pair<NS>(r[0][0], r[0][1], q[0]);
-        gb_split_pair<NS>(r[0][2], r[0][3], q[1]);
-        gb_split_pair<NS>(r[1][0], r[1][1], q[2]);
-        gb_split_pair<NS>(r[1][2], r[1][3], q[3]);
+        split_planes<NS>(r[0][0], r[0][1], q[0]);
+        split_planes<NS>(r[0][2], r[0][3], q[1]);
+        split_planes<NS>(r[1][0], r[1][1], q[2]);
+        split_planes<NS>(r[1][2], r[1][3], q[3]);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
@@ -335,14 +307,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
                 b[1][s] = *reinterpret_cast<const u32x4*>(pb + 32 * RS + s * 64 + m * 32);
             }
             // plane-product outer, accumulator inner: consecutive MFMAs never depend on each other
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-            for (int q = (NS == 1 ? 5 : 0); q < 6; ++q)
+            for (int q = 0; q < Planes<NS>::NPROD; ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = gb_mfma(a[i][NS == 1 ? 0 : PA[q]], b[j][NS == 1 ? 0 : PB[q]], acc[i][j]);
+                        acc[i][j] = mfma_planes<NS>(a[i][Planes<NS>::A[q]], b[j][Planes<NS>::B[q]], acc[i][j]);
         }
         if (more) {
             wait_all();                 // X rows (and, being older, the DMA pieces of this wave) have landed
@@ -482,10 +453,10 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             f32x4 r0 = ra[2 * hh], r1 = ra[2 * hh + 1];
             if (!oka) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
             unsigned q[4][NS];
-            gb_split_pair<NS>(r0[0], r0[1], q[0]);
-            gb_split_pair<NS>(r0[2], r0[3], q[1]);
-            gb_split_pair<NS>(r1[0], r1[1], q[2]);
-            gb_split_pair<NS>(r1[2], r1[3], q[3]);
+            split_planes<NS>(r0[0], r0[1], q[0]);
+            split_planes<NS>(r0[2], r0[3], q[1]);
+            split_planes<NS>(r1[0], r1[1], q[2]);
+            split_planes<NS>(r1[2], r1[3], q[3]);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
@@ -529,14 +500,13 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
                 b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
                 b[1][s] = *reinterpret_cast<const u32x4*>(pb + 32 * RS + s * 64 + m * 32);
             }
-            constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-            for (int q = (NS == 1 ? 5 : 0); q < 6; ++q)
+            for (int q = 0; q < Planes<NS>::NPROD; ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = gb_mfma(a[i][NS == 1 ? 0 : PA[q]], b[j][NS == 1 ? 0 : PB[q]], acc[i][j]);
+                        acc[i][j] = mfma_planes<NS>(a[i][Planes<NS>::A[q]], b[j][Planes<NS>::B[q]], acc[i][j]);
         }
         __builtin_amdgcn_s_waitcnt(0x0070);              // all fragment reads returned before the tile is overwritten
     }
@@ -628,17 +598,20 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         p.tiles_n = ceil_div(d->N, GO_BN);
         p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
         if (d->precision == EV2H_PREC_BF16X3) return launch_go<3>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_F16X2) return launch_go<2>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_BF16) return launch_go<1>(p, (const char*)d->Ws, (hipStream_t)stream);
     }
     if (d->Ws) {   // host-packed plane images of W: wide tile, W streamed by LDS-DMA
         p.tiles_n = ceil_div(d->N, GW_BN);
         p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
         if (d->precision == EV2H_PREC_BF16X3) return launch_gw<3>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_F16X2) return launch_gw<2>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_BF16) return launch_gw<1>(p, (const char*)d->Ws, (hipStream_t)stream);
     }
     p.tiles_n = ceil_div(d->N, GB_BN);
     p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
     if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_F16X2) return launch_gb<2>(p, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_BF16) return launch_gb<1>(p, (hipStream_t)stream);
     ev2h_set_error("ev2h_gemm: unknown precision %d", d->precision);
     return EV2H_ERR_ARG;

@@ -1,0 +1,59 @@
+// Operand planes of the matrix-pipe kernels (sa_mlp_bf16.hip, gemm_bf16.hip): every fp32 operand is represented by NS
+// 16-bit planes and a product x*w by a few plane products accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16}.
+//   NS = 1  "bf16"    one bf16 plane (round to nearest even), 1 product                      -- BASELINE.json config 3
+//   NS = 2  "f16x2"   x = h + l, two fp16 planes (h = rne(x), l = rne(x - h)): 11 + 11 mantissa bits; products
+//                     hl, lh, hh (the dropped ll term is O(2^-22)); |x| must stay below 65504, values whose low
+//                     plane is an fp16 subnormal keep an absolute error <= 2^-25 (the MFMA honours subnormals:
+//                     tools/ubench/mfma_f16_denorm.hip)
+//   NS = 3  "bf16x3"  x = h + m + l, three bf16 planes by exact truncation (8 + 8 + 8 bits); products hl, lh, mm,
+//                     hm, mh, hh (dropped terms O(2^-24)); full fp32 range
+// Smallest terms are accumulated first.  The same splits are applied to the weights on the host (pack.py).
+#pragma once
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NS> struct Planes;
+template <> struct Planes<1> { static constexpr int NPROD = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
+template <> struct Planes<2> { static constexpr int NPROD = 3; static constexpr int A[3] = {0, 1, 0}, B[3] = {1, 0, 0}; };
+template <> struct Planes<3> { static constexpr int NPROD = 6; static constexpr int A[6] = {0, 2, 1, 0, 1, 0}, B[6] = {2, 0, 1, 1, 0, 0}; };
+
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_planes(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (NS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float relu_bits(float x) {     // max(x, 0) as one integer max: no canonicalisation op, -0 -> +0
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+__device__ __forceinline__ unsigned pack_hi16(float x1, float x0) {     // upper halves of x1 : x0, one v_perm_b32
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_hi16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// two fp32 values -> NS packed plane words (element 0 in the low half-word).  Residual subtracts stay scalar: packed
+// fp32 VALU ops are slower than two plain ones on gfx950 (the build also passes -fno-slp-vectorize).
+template <int NS>
+__device__ __forceinline__ void split_planes(float x0, float x1, unsigned (&o)[NS]) {
+    if constexpr (NS == 1) {
+        o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+    } else if constexpr (NS == 2) {
+        const f16x2 h = __builtin_convertvector(f32x2{x0, x1}, f16x2);                            // v_cvt_pk_f16_f32 (RNE)
+        o[0] = __builtin_bit_cast(unsigned, h);
+        const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];                                 // exact
+        o[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, f16x2));
+    } else {
+        o[0] = pack_hi16(x1, x0);
+        const float r0 = x0 - trunc_hi16(x0), r1 = x1 - trunc_hi16(x1);                           // exact
+        o[1] = pack_hi16(r1, r0);
+        const float q0 = r0 - trunc_hi16(r0), q1 = r1 - trunc_hi16(r1);
+        o[2] = pack_hi16(q1, q0);
+    }
+}

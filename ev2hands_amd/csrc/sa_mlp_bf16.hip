@@ -1,5 +1,6 @@
-// Fused grouped set-abstraction MLP on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
-// rate), same structure and same reference lines as sa_mlp.hip (pointnet2_utils.py:244-257):
+// Fused grouped set-abstraction MLP on the 16-bit matrix pipe (v_mfma_f32_32x32x16_{bf16,f16}, 16x the fp32 MFMA
+// rate), same structure and same reference lines as sa_mlp.hip (pointnet2_utils.py:244-257); operand planes: planes.hpp
+//   NS = 2  "f16x2": two fp16 planes per operand, 3 plane products -- fp32-class accuracy at 3/16 of the fp32 MFMA cost
 //   NS = 3  "bf16x3": every fp32 operand is split exactly into three bf16 planes (8+8+8 mantissa bits,
 //           truncation split x = h + m + l) and the six products hh, hm, mh, mm, hl, lh are accumulated in
 //           fp32 -- dropped terms are O(2^-24), i.e. fp32-class accuracy at 6/16 of the fp32 MFMA cost;
@@ -9,13 +10,10 @@
 // Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
 // ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
 // (global_load_lds_dwordx4, no staging registers); two buffers, one barrier per tile.
-#include "common.hpp"
+#include "planes.hpp"
 #include "ev2hands_hip.h"
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SaBP {
     const float* P1; int ldp;
@@ -58,71 +56,10 @@ struct SaBCfg {
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
 };
 
-__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// two fp32 -> packed bf16 pair(s): element 0 in the low half-word
-template <int NS>
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&o)[NS]) {
-    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-    if constexpr (NS == 1) {
-        const unsigned r0 = u0 + 0x7fffu + ((u0 >> 16) & 1u), r1 = u1 + 0x7fffu + ((u1 >> 16) & 1u);   // RNE
-        o[0] = (r1 & 0xffff0000u) | (r0 >> 16);
-    } else {
-        // exact truncation split: x = h + m + l, each piece has <= 8 significant bits
-        o[0] = (u1 & 0xffff0000u) | (u0 >> 16);
-        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
-        const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-        o[1] = (v1 & 0xffff0000u) | (v0 >> 16);
-        const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-        o[2] = (__float_as_uint(s1) & 0xffff0000u) | (__float_as_uint(s0) >> 16);
-    }
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float relu_bits(float x) {     // max(x, 0) as one integer max: no canonicalisation op, -0 -> +0
-    const int i = __builtin_bit_cast(int, x);
-    return __builtin_bit_cast(float, i > 0 ? i : 0);
-}
-__device__ __forceinline__ unsigned pack_hi16(float x1, float x0) {     // bf16 (truncated) of x1 : x0, one v_perm_b32
-    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-// same planes as split_pair with v_perm packs; the residual subtracts stay scalar (packed fp32 VALU ops are slower than
-// two plain ones on gfx950 next to MFMAs, which is also why the build passes -fno-slp-vectorize)
-template <int NS>
-__device__ __forceinline__ void split_pair_v(f32x2 x, unsigned (&o)[NS]) {
-    if constexpr (NS == 1) {
-        split_pair<1>(x[0], x[1], o);
-    } else {
-        o[0] = pack_hi16(x[1], x[0]);
-        const float r0 = x[0] - __uint_as_float(__float_as_uint(x[0]) & 0xffff0000u);
-        const float r1 = x[1] - __uint_as_float(__float_as_uint(x[1]) & 0xffff0000u);
-        o[1] = pack_hi16(r1, r0);
-        const float q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
-        const float q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
-        o[2] = pack_hi16(q1, q0);
-    }
-}
-
-// acc += sum over the kept plane products of A-plane x B-plane (smallest terms first)
-template <int NS>
-__device__ __forceinline__ f32x16 mfma_split(const u32x4 (&a)[NS], const u32x4 (&b)[NS], f32x16 acc) {
-    if constexpr (NS == 1) {
-        return mfma_bf16(a[0], b[0], acc);
-    } else {
-        acc = mfma_bf16(a[0], b[2], acc);
-        acc = mfma_bf16(a[2], b[0], acc);
-        acc = mfma_bf16(a[1], b[1], acc);
-        acc = mfma_bf16(a[0], b[1], acc);
-        acc = mfma_bf16(a[1], b[0], acc);
-        return mfma_bf16(a[0], b[0], acc);
-    }
-}
-
 template <int C1, int C2, int C3, int NS>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
+    using PL = Planes<NS>;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wt0 = smem;
@@ -221,8 +158,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
                 unsigned lo[NS], hi[NS];
-                split_pair_v<NS>(f32x2{relu_bits(v[0]), relu_bits(v[1])}, lo);
-                split_pair_v<NS>(f32x2{relu_bits(v[2]), relu_bits(v[3])}, hi);
+                split_planes<NS>(relu_bits(v[0]), relu_bits(v[1]), lo);
+                split_planes<NS>(relu_bits(v[2]), relu_bits(v[3]), hi);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 0] = lo[s];
@@ -247,16 +184,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     a0[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t0 * RS2 + s * 64 + m0 * 16);
                     a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t1 * RS2 + s * 64 + m1 * 16);
                 }
-                if constexpr (NS == 1) {
-                    h2[t0] = mfma_bf16(a0[0], bp[m0][0], h2[t0]);
-                    h2[t1] = mfma_bf16(a1[0], bp[m1][0], h2[t1]);
-                } else {
-                    constexpr int ia[6] = {0, 2, 1, 0, 1, 0}, ib[6] = {2, 0, 1, 1, 0, 0};   // smallest terms first
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        h2[t0] = mfma_bf16(a0[ia[j]], bp[m0][ib[j]], h2[t0]);
-                        h2[t1] = mfma_bf16(a1[ia[j]], bp[m1][ib[j]], h2[t1]);
-                    }
+                for (int j = 0; j < PL::NPROD; ++j) {
+                    h2[t0] = mfma_planes<NS>(a0[PL::A[j]], bp[m0][PL::B[j]], h2[t0]);
+                    h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
                 }
             }
             STAMP(4 + 4 * c);
@@ -274,7 +205,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 unsigned o[NS];
-                split_pair_v<NS>(f32x2{relu_bits(h2[t][2 * k]), relu_bits(h2[t][2 * k + 1])}, o);
+                split_planes<NS>(relu_bits(h2[t][2 * k]), relu_bits(h2[t][2 * k + 1]), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
@@ -307,15 +238,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                             w[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (32 * t + 16 * m) * 2);
                         }
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
-                        if constexpr (NS == 1) {
-                            if (m == 0) acc = mfma_bf16(a[0], w[0], acc); else acc1 = mfma_bf16(a[0], w[0], acc1);
-                        } else {
-                            acc = mfma_bf16(a[0], w[2], acc);
-                            acc1 = mfma_bf16(a[2], w[0], acc1);
-                            acc = mfma_bf16(a[1], w[1], acc);
-                            acc1 = mfma_bf16(a[0], w[1], acc1);
-                            acc = mfma_bf16(a[1], w[0], acc);
-                            acc1 = mfma_bf16(a[0], w[0], acc1);
+#pragma unroll
+                        for (int j = 0; j < PL::NPROD; ++j) {
+                            if (((2 * t + m) * PL::NPROD + j) & 1) acc1 = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc1);
+                            else acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
                         }
                     }
                 }
@@ -387,6 +313,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);
+    if (d->precision == EV2H_PREC_F16X2) return dispatch_sab<2>(p, d->C1, d->C2, d->C3, st);
     if (d->precision == EV2H_PREC_BF16) return dispatch_sab<1>(p, d->C1, d->C2, d->C3, st);
     ev2h_set_error("ev2h_sa_mlp_max: unknown precision %d", d->precision);
     return EV2H_ERR_ARG;

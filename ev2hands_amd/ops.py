@@ -108,8 +108,8 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
 
 def make_w_image(W: torch.Tensor, precision: str, rows: int = 128) -> torch.Tensor:
     """bf16 plane images of a dense weight for the bf16 GEMM kernels (host-side packing, do it once per weight)."""
-    from .pack import gemm_bf16_w_image
-    return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), {"bf16": 1, "bf16x3": 3}[precision], rows)).to(W.device)
+    from .pack import NS_OF, gemm_bf16_w_image
+    return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), NS_OF[precision], rows)).to(W.device)
 
 
 def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32") -> torch.Tensor:
@@ -127,9 +127,9 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     d.precision = _lib.PREC[precision]
     keep = []
     if precision != "f32":
-        from .pack import sa_bf16_images
+        from .pack import NS_OF, sa_bf16_images
         i2, i3 = sa_bf16_images(W2[:C2].detach().cpu().double().numpy(), W3[:, :C2].detach().cpu().double().numpy(),
-                                {"bf16": 1, "bf16x3": 3}[precision])
+                                NS_OF[precision])
         keep = [torch.from_numpy(i2).to(P1.device), torch.from_numpy(i3).to(P1.device)]
         d.W2s, d.W3s = keep[0].data_ptr(), keep[1].data_ptr()
     _lib.check(_lib.lib().ev2h_sa_mlp_max(C.byref(d), _st()), "ev2h_sa_mlp_max")

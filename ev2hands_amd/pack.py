@@ -56,11 +56,21 @@ def _up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+NS_OF = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}     # operand planes per precision (csrc/planes.hpp)
+
+
 def split_bf16_planes(a: np.ndarray, ns: int):
-    """fp32 array -> list of `ns` uint16 arrays of bf16 bit patterns.
-    ns == 1: round to nearest even.  ns == 3: exact truncation split a = h + m + l (8 + 8 + 8 mantissa bits),
-    the same split the kernels apply to activations (csrc/sa_mlp_bf16.hip: split_pair)."""
+    """fp32 array -> list of `ns` uint16 arrays of 16-bit plane patterns, the same splits the kernels apply to
+    activations (csrc/planes.hpp: split_planes).
+    ns == 1: bf16, round to nearest even.  ns == 2: two fp16 planes, a = h + l with h = rne(a), l = rne(a - h).
+    ns == 3: exact truncation split into three bf16 planes a = h + m + l (8 + 8 + 8 mantissa bits)."""
     x = np.ascontiguousarray(a, dtype=np.float32)
+    if ns == 2:
+        if x.size and float(np.abs(x).max()) >= 65504.0:
+            raise ValueError("f16x2 needs |weight| < 65504 (fp16 range); use precision='bf16x3' or 'f32' for this checkpoint")
+        h = x.astype(np.float16)
+        l = (x - h.astype(np.float32)).astype(np.float16)
+        return [h.view(np.uint16), l.view(np.uint16)]
     if ns == 1:
         u = x.view(np.uint32).astype(np.uint64)
         return [((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)]
@@ -135,7 +145,7 @@ class PackedWeights:
         self.device = torch.device(device)
         self.in_channels = in_channels
         self.precision = precision
-        self.ns = {"f32": 0, "bf16": 1, "bf16x3": 3}[precision]
+        self.ns = NS_OF[precision]
         self._keep = []
         self.tensors = {}
         self.struct = _lib.Weights()

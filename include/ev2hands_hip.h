@@ -35,9 +35,13 @@ typedef void* ev2h_stream_t; /* hipStream_t */
  *  F32     v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (default);
  *  BF16X3  each fp32 operand split exactly into 3 bf16 planes, 6 plane products on
  *          v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class accuracy (dropped terms O(2^-24));
+ *  F16X2   each fp32 operand split into 2 fp16 planes (11 + 11 mantissa bits), 3 plane products on
+ *          v_mfma_f32_32x32x16_f16 with fp32 accumulation: dropped terms O(2^-22), operands must stay below 65504
+ *          in magnitude (weights are checked at pack time), absolute error <= 2^-25 for tiny operands;
  *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3). */
 #define EV2H_PREC_F32 0
 #define EV2H_PREC_BF16 1
+#define EV2H_PREC_F16X2 2
 #define EV2H_PREC_BF16X3 3
 
 /* ---- library ------------------------------------------------------------------------------- */
@@ -92,7 +96,7 @@ typedef struct ev2h_gemm_desc {
     int taps;                    /* 1, or 3 = Conv1d(k=3, padding=1) along rows, zero padded per sequence */
     int rows_per_seq;            /* rows per window when taps == 3                                      */
     int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
-    int precision;               /* EV2H_PREC_*; BF16 / BF16X3 need K % 8 == 0 (operands are split on the fly) */
+    int precision;               /* EV2H_PREC_*; all but F32 need K % 8 == 0 (operands are split on the fly) */
     const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in (ws_tile_rows)-row x 32-k LDS
                                     tiles (ev2hands_amd/pack.py: gemm_bf16_w_image); NULL = split W on the fly  */
     int ws_tile_rows;            /* 128 (three 4-wave workgroups per CU) or 256 (one 8-wave workgroup)           */

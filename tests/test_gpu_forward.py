@@ -97,7 +97,7 @@ def check_against(out, net, ref, trace, B, N):
     assert same
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("kind,C,N,B,seed", [("U", 4, 2048, 2, 0), ("E", 5, 2048, 2, 1), ("E", 4, 2048, 3, 4), ("U", 5, 256, 2, 2),
                                               ("E", 4, 8192, 1, 5), ("U", 5, 1000, 2, 6)])
 def test_forward_matches_oracle(kind, C, N, B, seed, precision):
@@ -117,7 +117,7 @@ def test_forward_matches_oracle(kind, C, N, B, seed, precision):
     check_against(out, net, ref, trace, B, N)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
 def test_forward_matches_reference_fixture(path, precision):
     """Against numbers produced by the reference itself (oracle/make_golden.py)."""
@@ -230,7 +230,7 @@ def test_bf16_mode_reports_mpjpe_and_argmax_agreement():
     assert mpjpe_mm < 5.0 and agree > 0.97
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_full_size_batch_properties(precision):
     """BASELINE.json config 2 size (B=64, N=2048, C=4), too slow for the CPU oracle: size-independent properties instead --
     permuting the windows of a batch permutes every output bit-exactly (windows are independent, weights shared), and the
@@ -252,12 +252,12 @@ def test_full_size_batch_properties(precision):
     assert torch.equal(a["l"][pc], b["class_logits"]) and torch.equal(a["v"][pc], b["left"]["vertices"])
     assert torch.equal(a["j"][pc], b["right"]["j3d"]) and torch.equal(a["p"][pc], b["right"]["betas"])
     assert torch.isfinite(a["l"]).all() and torch.isfinite(a["v"]).all()
-    if precision == "bf16x3":
+    if precision != "f32":
         net32, _, _ = make_net(C, seed, precision="f32")
         net32.net.fps_init = inits
         with torch.no_grad():
             r = net32(xyz)
         assert rel(a["l"], r["class_logits"]) < TOL and rel(a["v"], r["left"]["vertices"]) < TOL
         agree = float((a["l"].argmax(1) == r["class_logits"].argmax(1)).float().mean())
-        print(f"bf16x3 vs f32 at B=64: logits rel {rel(a['l'], r['class_logits']):.2e}, argmax agreement {agree * 100:.4f} %")
+        print(f"{precision} vs f32 at B=64: logits rel {rel(a['l'], r['class_logits']):.2e}, argmax agreement {agree * 100:.4f} %")
         assert agree == 1.0

@@ -110,7 +110,7 @@ GEMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision,tol,wrows", [("f32", 2e-6, 128), ("bf16x3", 3e-6, 128), ("bf16x3", 3e-6, 256), ("bf16", 2e-2, 128),
+@pytest.mark.parametrize("precision,tol,wrows", [("f32", 2e-6, 128), ("bf16x3", 3e-6, 128), ("bf16x3", 3e-6, 256), ("f16x2", 6e-6, 128), ("f16x2", 6e-6, 256), ("bf16", 2e-2, 128),
                                                  ("bf16", 2e-2, 256)])
 @pytest.mark.parametrize("M,N,K,relu,post,taps,rowmax,group", GEMM_CASES)
 def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
@@ -150,7 +150,7 @@ def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
 SA_CASES = [(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128), (128, 128, 256, 64), (128, 196, 256, 128)]
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("bf16x3", 4e-6), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("bf16x3", 4e-6), ("f16x2", 8e-6), ("bf16", 2e-2)])
 @pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
 def test_sa_mlp_max(C1, C2, C3, K, precision, tol):
     _need_gpu()

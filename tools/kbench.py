@@ -45,7 +45,7 @@ def bench_sa(B=256, precision="f32"):
             import ctypes as C
             from ev2hands_amd import _lib
             from ev2hands_amd.pack import sa_bf16_images
-            i2, i3 = sa_bf16_images(W2[:C2].cpu().double().numpy(), W3[:, :C2].cpu().double().numpy(), {"bf16": 1, "bf16x3": 3}[precision])
+            i2, i3 = sa_bf16_images(W2[:C2].cpu().double().numpy(), W3[:, :C2].cpu().double().numpy(), _lib.PREC[precision])
             i2, i3 = torch.from_numpy(i2).cuda(), torch.from_numpy(i3).cuda()
             out = torch.empty(B, S, C3, device=d)
             dd = _lib.SaDesc()
@@ -115,13 +115,13 @@ if __name__ == "__main__":
     if what in ("sa", "all"):
         bench_sa()
     if what in ("sab", "all"):
-        bench_sa(precision="bf16x3")
-        bench_sa(precision="bf16")
+        for prec in os.environ.get("KBENCH_PREC", "bf16x3,f16x2,bf16").split(","):
+            bench_sa(precision=prec)
     if what in ("events", "all"):
         bench_events()
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemmb", "all"):
-        bench_gemm(precision="bf16x3", rows=128)
+        for prec in os.environ.get("KBENCH_PREC", "bf16x3,f16x2,bf16").split(","):
+            bench_gemm(precision=prec, rows=128)
         bench_gemm(precision="bf16x3", rows=256)
-        bench_gemm(precision="bf16", rows=128)
