@@ -10,6 +10,7 @@
 // Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
 // ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
 // (global_load_lds_dwordx4, no staging registers); two buffers, one barrier per tile.
+#include <cstdlib>
 #include "planes.hpp"
 #include "ev2hands_hip.h"
 
@@ -26,6 +27,7 @@ struct SaBP {
     float* out; int ldo;
     int B, Npts, S, K;
     int nblk;
+    int per_blk;                          // resident variant: groups per workgroup (multiple of 8)
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -53,29 +55,35 @@ struct SaBCfg {
     static constexpr int TB3 = 32 * RS3;
     static constexpr int TILE = ((TB2 > TB3 ? TB2 : TB3) + 1023) / 1024 * 1024;
     static constexpr int LDS_BYTES = 2 * TILE + C1 * 16 + T2 * 32 * 4;
+    // resident variant: every tile image of the module stays in LDS for the lifetime of the (persistent) workgroup
+    static constexpr int RES_W = (NC1 * TB2 + T3 * TB3 + 1023) / 1024 * 1024;
+    static constexpr int RES_LDS_BYTES = RES_W + C1 * 16 + T2 * 32 * 4;
+    static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
 };
 
-template <int C1, int C2, int C3, int NS>
+// RES = false: weight tiles are streamed, two LDS buffers, one barrier per tile (any MLP width).
+// RES = true : all tile images of the module fit in LDS (the three narrow MLPs of sa1): they are loaded once by a
+//              persistent workgroup whose waves then walk their groups with NO barrier and no DMA in the loop -- the
+//              waves drift apart, so one wave's split (VALU) phases run under the other waves' MFMA phases, and a tile
+//              step no longer pays the DMA issue / wait / barrier that dominate when a tile holds only 6-18 MFMAs.
+template <int C1, int C2, int C3, int NS, bool RES>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
+    constexpr int WBYTES = RES ? Cfg::RES_W : 2 * Cfg::TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wt0 = smem;
     char* wt1 = smem + Cfg::TILE;
-    f32x4* sW1xT = reinterpret_cast<f32x4*>(smem + 2 * Cfg::TILE);     // per 4 channels: x[4], y[4], z[4]
-    float* sb2 = reinterpret_cast<float*>(smem + 2 * Cfg::TILE + C1 * 16);
+    f32x4* sW1xT = reinterpret_cast<f32x4*>(smem + WBYTES);     // per 4 channels: x[4], y[4], z[4]
+    float* sb2 = reinterpret_cast<float*>(smem + WBYTES + C1 * 16);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
-    const int g = L * SAB_WAVES + wave;
-    const bool valid = g < ngroups;
-    const int gg = valid ? g : ngroups - 1;
-    const int b = gg / p.S;
 
     for (int i = tid; i < C1; i += SAB_THREADS) {
         const float4 w = p.W1x[i];
@@ -95,6 +103,22 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     auto dma_w2 = [&](int c, char* dst) { dma_tile(p.W2s + (size_t)c * Cfg::TB2, dst, Cfg::TB2); };
     auto dma_w3 = [&](int u, char* dst) { dma_tile(p.W3s + (size_t)u * Cfg::TB3, dst, Cfg::TB3); };
 
+    int buf = 0;
+    if constexpr (RES) {
+        dma_tile(p.W2s, smem, NC1 * Cfg::TB2);
+        dma_tile(p.W3s, smem + NC1 * Cfg::TB2, T3 * Cfg::TB3);
+    } else {
+        dma_w2(0, wt0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // RES: logical block L owns the contiguous groups [L * p.per_blk, (L + 1) * p.per_blk), wave w takes every 8th of them
+    const int g_end = RES ? min(ngroups, (L + 1) * p.per_blk) : ngroups;
+  for (int g = (RES ? L * p.per_blk : L * SAB_WAVES) + wave; RES ? g < g_end : true; g += SAB_WAVES) {
+    const bool valid = g < ngroups;
+    const int gg = valid ? g : ngroups - 1;
+    const int b = gg / p.S;
     float mrun[T3];
 #pragma unroll
     for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
@@ -102,11 +126,6 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const float4 ctr = p.ctr4[gg];
     const int nstrips = p.K >> 5;
     const int32_t* gi = p.gidx + (size_t)gg * p.K;
-
-    int buf = 0;
-    dma_w2(0, wt0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
 #ifdef EV2H_SAB_TIMELINE
     const bool dbgw = (blockIdx.x == 300 && tid == 0);
@@ -141,9 +160,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll 1
         for (int c = 0; c < NC1; ++c) {
             STAMP(2 + 4 * c);
-            char* cur = buf ? wt1 : wt0;
+            char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0);
             char* nxt = buf ? wt0 : wt1;
-            if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt);
+            if constexpr (!RES) { if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt); }
             if (!Cfg::PREFETCH_P1 && c > 0) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
@@ -191,8 +210,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 }
             }
             STAMP(4 + 4 * c);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued above has landed
-            __syncthreads();
+            if constexpr (!RES) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued above has landed
+                __syncthreads();
+            }
             STAMP(5 + 4 * c);
             buf ^= 1;
         }
@@ -216,11 +237,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll 1
         for (int u = 0; u < T3; ++u) {
             STAMP(40 + 4 * u);
-            char* cur = buf ? wt1 : wt0;
+            char* cur = RES ? smem + NC1 * Cfg::TB2 + u * Cfg::TB3 : (buf ? wt1 : wt0);
             char* nxt = buf ? wt0 : wt1;
             const bool more_w3 = (u + 1 < T3);
             const bool more = more_w3 || (strip + 1 < nstrips);
-            if (more_w3) dma_w3(u + 1, nxt); else if (more) dma_w2(0, nxt);
+            if constexpr (!RES) { if (more_w3) dma_w3(u + 1, nxt); else if (more) dma_w2(0, nxt); }
             // two accumulators take alternate plane products (see layer 2); their sum is the tile
             f32x16 acc, acc1;
 #pragma unroll
@@ -256,8 +277,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
             STAMP(42 + 4 * u);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if constexpr (!RES) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             STAMP(43 + 4 * u);
             buf ^= 1;
         }
@@ -269,18 +292,40 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
         if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v + p.b3[32 * u + l31], 0.f);
     }
+    if constexpr (!RES) break;
+  }
 }
 
 template <int C1, int C2, int C3, int NS>
-int launch_sab(const SaBP& p, hipStream_t st) {
+int launch_sab(SaBP p, hipStream_t st) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
+    static const bool streamed_only = getenv("EV2H_SA_STREAMED") != nullptr;      // A/B switch for the resident variant
+    if constexpr (Cfg::FITS_RESIDENT) {
+        if (!streamed_only) {
+            static int wg_per_cu = 0;
+            if (!wg_per_cu) {
+                auto k = sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true>;
+                EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::RES_LDS_BYTES));
+                int n = 0;
+                EV2H_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SAB_THREADS, Cfg::RES_LDS_BYTES));
+                wg_per_cu = n > 0 ? n : 1;
+            }
+            const int ngroups = p.B * p.S;
+            const int want = 256 * wg_per_cu;                                   // one resident wave of workgroups
+            p.per_blk = ceil_div(ceil_div(ngroups, want), SAB_WAVES) * SAB_WAVES;
+            p.nblk = ceil_div(ngroups, p.per_blk);
+            sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true><<<p.nblk, SAB_THREADS, Cfg::RES_LDS_BYTES, st>>>(p);
+            EV2H_CHECK_LAUNCH();
+            return EV2H_OK;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS>),
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
         attr_set = true;
     }
-    sa_mlp_max_bf16_kernel<C1, C2, C3, NS><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
+    sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
