@@ -398,17 +398,21 @@ int launch_gw(const GemmBP& p, const char* Ws, hipStream_t st) {
 // tools/ubench/mfma_lds.hip).  W arrives as 128-row plane images by LDS-DMA, X is split on the fly.
 constexpr int GO_BN = 128, GO_THREADS = 256;
 
-template <int NS>
+// TAP3 (Conv1d k=3 along the rows, Kc % 32 == 0, rows_per_seq % 128 == 0): the three taps of one 32-wide channel chunk
+// are the same 130 rows of X shifted by one, so the chunk is loaded and split ONCE (128 rows + a one-row halo each side,
+// zero at the window ends) and the three W tiles of that chunk are multiplied against row-shifted views of it.
+template <int NS, bool TAP3>
 struct GOCfg {
     static constexpr int RS = NS * 64 + 16;
-    static constexpr int A_BYTES = GB_BM * RS;
+    static constexpr int A_ROWS = GB_BM + (TAP3 ? 2 : 0);
+    static constexpr int A_BYTES = A_ROWS * RS;
     static constexpr int B_BYTES = GO_BN * RS;
     static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
 };
 
-template <int NS>
+template <int NS, bool TAP3>
 __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP p, const char* __restrict__ Ws) {
-    using Cfg = GOCfg<NS>;
+    using Cfg = GOCfg<NS, TAP3>;
     constexpr int RS = Cfg::RS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
@@ -423,9 +427,14 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
     const int half = lane >> 5, l31 = lane & 31;
     const int lrow = tid >> 1, lseg = tid & 1;            // loader: row, 16-wide k half
     const int nk = (p.K + GB_BK - 1) / GB_BK;
-    f32x4 ra[4];
-    bool oka = true;
+    f32x4 ra[4], rh[4];
+    bool oka = true, okh = true;
 
+    auto load16 = [&](const float* g, f32x4 (&r)[4]) {
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(g) : "memory");
+    };
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 16;
         int tap = 0, kc = k;
@@ -438,20 +447,32 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             ok = ok && (pos >= 0) && (pos < p.rows_per_seq);
             src = (long)m + tap - 1;
         }
-        const float* g = p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0);
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
-                     : "=&v"(ra[0]), "=&v"(ra[1]), "=&v"(ra[2]), "=&v"(ra[3]) : "v"(g) : "memory");
+        load16(p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0), ra);
         oka = ok;
     };
-    auto wait_all = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
+    // TAP3: chunk kc of the centre rows (LDS rows 1..128) and, threads 0..3, of the two halo rows (LDS rows 0 and 129)
+    auto gload3 = [&](int kc) {
+        const int k = kc * GB_BK + lseg * 16;
+        const int m = m0 + lrow;
+        oka = m < p.M;
+        load16(p.X + (oka ? (long)m : 0) * p.ldx + k, ra);
+        if (tid < 4) {
+            const long mh = (tid >> 1) ? (long)m0 + GB_BM : (long)m0 - 1;
+            okh = (tid >> 1) ? ((m0 + GB_BM) % p.rows_per_seq != 0 && mh < p.M) : (m0 % p.rows_per_seq != 0);
+            load16(p.X + (okh ? mh : 0) * p.ldx + k, rh);
+        }
     };
-    auto swrite = [&]() {
+    auto wait_all = [&]() {
+        if constexpr (TAP3)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rh[0]), "+v"(rh[1]), "+v"(rh[2]), "+v"(rh[3]) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
+    };
+    auto swrite_row = [&](const f32x4 (&r)[4], bool ok, int ldsrow) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            f32x4 r0 = ra[2 * hh], r1 = ra[2 * hh + 1];
-            if (!oka) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
+            f32x4 r0 = r[2 * hh], r1 = r[2 * hh + 1];
+            if (!ok) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
             unsigned q[4][NS];
             split_planes<NS>(r0[0], r0[1], q[0]);
             split_planes<NS>(r0[2], r0[3], q[1]);
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
-                *reinterpret_cast<u32x4*>(sA + lrow * RS + s * 64 + lseg * 32 + hh * 16) = v;
+                *reinterpret_cast<u32x4*>(sA + ldsrow * RS + s * 64 + lseg * 32 + hh * 16) = v;
             }
         }
     };
@@ -480,15 +501,8 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt) __builtin_amdgcn_s_barrier();           // everyone finished reading the previous tile
-        dma_b(kt);
-        gload(kt);
-        wait_all();
-        swrite();
-        __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
-        const char* pa = sA + (wm * 64 + l31) * RS + half * 16;
+    auto mma_tile = [&](int arow) {
+        const char* pa = sA + (wm * 64 + l31 + arow) * RS + half * 16;
         const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -500,6 +514,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
                 b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
                 b[1][s] = *reinterpret_cast<const u32x4*>(pb + 32 * RS + s * 64 + m * 32);
             }
+            // plane-product outer, accumulator inner: consecutive MFMAs never depend on each other
 #pragma unroll
             for (int q = 0; q < Planes<NS>::NPROD; ++q)
 #pragma unroll
@@ -508,7 +523,41 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = mfma_planes<NS>(a[i][Planes<NS>::A[q]], b[j][Planes<NS>::B[q]], acc[i][j]);
         }
-        __builtin_amdgcn_s_waitcnt(0x0070);              // all fragment reads returned before the tile is overwritten
+        __builtin_amdgcn_s_waitcnt(0x0070);              // all fragment reads returned before a tile is overwritten
+    };
+    if constexpr (TAP3) {
+        const int nkc = p.Kc / GB_BK;
+        for (int kc = 0; kc < nkc; ++kc) {
+            if (kc) __builtin_amdgcn_s_barrier();        // everyone finished reading the previous chunk
+            dma_b(kc);
+            gload3(kc);
+            wait_all();
+            swrite_row(ra, oka, lrow + 1);
+            if (tid < 4) swrite_row(rh, okh, (tid >> 1) ? GB_BM + 1 : 0);
+            __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+            for (int tap = 0; tap < 3; ++tap) {
+                if (tap) {
+                    __builtin_amdgcn_s_barrier();        // sB is free
+                    dma_b(tap * nkc + kc);
+                    __builtin_amdgcn_s_waitcnt(0x0070);
+                    __builtin_amdgcn_s_barrier();
+                }
+                mma_tile(tap);                           // output row j of tap t reads X row j + t - 1 = LDS row j + t
+            }
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt) __builtin_amdgcn_s_barrier();        // everyone finished reading the previous tile
+            dma_b(kt);
+            gload(kt);
+            wait_all();
+            swrite_row(ra, oka, lrow);
+            __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            mma_tile(0);
+        }
     }
 
     const float* bias = p.bias;
@@ -567,17 +616,25 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
     }
 }
 
-template <int NS>
-int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
+template <int NS, bool TAP3>
+int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS>::LDS_BYTES));
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS, TAP3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS, TAP3>::LDS_BYTES));
         attr_set = true;
     }
-    gemm_nt_bf16_occ_kernel<NS><<<p.nblk, GO_THREADS, GOCfg<NS>::LDS_BYTES, st>>>(p, Ws);
+    gemm_nt_bf16_occ_kernel<NS, TAP3><<<p.nblk, GO_THREADS, GOCfg<NS, TAP3>::LDS_BYTES, st>>>(p, Ws);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
+}
+
+template <int NS>
+int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
+    static const bool no_tap3 = getenv("EV2H_GEMM_NO_TAP3") != nullptr;       // A/B switch
+    if (p.taps == 3 && !no_tap3 && p.Kc % GB_BK == 0 && p.rows_per_seq % GB_BM == 0 && p.M % p.rows_per_seq == 0)
+        return launch_go_t<NS, true>(p, Ws, st);
+    return launch_go_t<NS, false>(p, Ws, st);
 }
 
 }  // namespace

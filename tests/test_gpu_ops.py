@@ -104,6 +104,7 @@ GEMM_CASES = [
     (5, 22, 1024, False, False, 1, 0, 0),
     (7, 1024, 512, True, True, 1, 0, 0),
     (512, 256, 256, True, True, 3, 0, 0),
+    (1024, 128, 64, True, False, 3, 0, 0),        # 256-row sequences: interior tile boundaries exercise the row halo
     (256, 512, 256, True, False, 1, 128, 0),
     (384, 256, 512, True, False, 1, 0, 128),
     (4096, 256, 576, True, False, 1, 0, 0),
@@ -124,7 +125,7 @@ def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
     pt = torch.from_numpy(synth.hash_normal("pt", (N,), 6)).float() if post else None
     Xd, Wd = X.double(), W.double()
     if taps == 3:
-        seq = 128
+        seq = 256 if M >= 1024 else 128
         Xs = Xd.view(M // seq, seq, K)
         z = torch.zeros(M // seq, 1, K, dtype=torch.float64)
         Xcat = torch.cat([torch.cat([z, Xs[:, :-1]], 1), Xs, torch.cat([Xs[:, 1:], z], 1)], 2).view(M, 3 * K)
