@@ -10,6 +10,7 @@
 // Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
 // ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
 // (global_load_lds_dwordx4, no staging registers); two buffers, one barrier per tile.
+#include <algorithm>
 #include <cstdlib>
 #include "planes.hpp"
 #include "ev2hands_hip.h"
@@ -27,7 +28,7 @@ struct SaBP {
     float* out; int ldo;
     int B, Npts, S, K;
     int nblk;
-    int per_blk;                          // resident variant: groups per workgroup (multiple of 8)
+    int per_xcd;                          // resident variant: groups per XCD (multiple of 8); nblk is a multiple of 8
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -113,9 +114,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // RES: logical block L owns the contiguous groups [L * p.per_blk, (L + 1) * p.per_blk), wave w takes every 8th of them
-    const int g_end = RES ? min(ngroups, (L + 1) * p.per_blk) : ngroups;
-  for (int g = (RES ? L * p.per_blk : L * SAB_WAVES) + wave; RES ? g < g_end : true; g += SAB_WAVES) {
+    // RES: XCD x (= blockIdx & 7, the dispatcher's round-robin) owns the contiguous groups [x * per_xcd, (x + 1) * per_xcd);
+    // its nblk/8 workgroups sweep that range together, 8 groups per workgroup per step, so that at any time one XCD works on
+    // a few neighbouring windows whose P1 tables and index lists stay in its L2 (a workgroup-contiguous split measured 4.5x
+    // the algorithmic HBM traffic: 32 windows in flight per XCD do not fit the 4 MB L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nbx = p.nblk >> 3;
+    const int g_end = RES ? min(ngroups, (xcd + 1) * p.per_xcd) : ngroups;
+  for (int g = (RES ? xcd * p.per_xcd + slot * SAB_WAVES : L * SAB_WAVES) + wave; RES ? g < g_end : true; g += nbx * SAB_WAVES) {
     const bool valid = g < ngroups;
     const int gg = valid ? g : ngroups - 1;
     const int b = gg / p.S;
@@ -312,8 +317,8 @@ int launch_sab(SaBP p, hipStream_t st) {
             }
             const int ngroups = p.B * p.S;
             const int want = 256 * wg_per_cu;                                   // one resident wave of workgroups
-            p.per_blk = ceil_div(ceil_div(ngroups, want), SAB_WAVES) * SAB_WAVES;
-            p.nblk = ceil_div(ngroups, p.per_blk);
+            p.per_xcd = ceil_div(ceil_div(ngroups, 8), SAB_WAVES) * SAB_WAVES;
+            p.nblk = 8 * std::min(want / 8, ceil_div(p.per_xcd, SAB_WAVES));
             sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true><<<p.nblk, SAB_THREADS, Cfg::RES_LDS_BYTES, st>>>(p);
             EV2H_CHECK_LAUNCH();
             return EV2H_OK;
