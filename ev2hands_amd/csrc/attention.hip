@@ -76,12 +76,25 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 acc[h * 4 + c] = fmaf(w[h][c].w, v.w, fmaf(w[h][c].z, v.z, fmaf(w[h][c].y, v.y, w[h][c].x * v.x)));
+        // 8 wave-wide sums with 10 shuffles instead of 48: every butterfly step halves the number of values a lane carries
+        // (lanes with the step's bit set keep the upper half of the values), then three plain steps finish the 8-lane groups
+        float r4[4], r2[2];
+        const bool hi32 = lane & 32, hi16 = lane & 16, hi8 = lane & 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = wave_sum_f32(acc[i]);
-        if (lane < 2) {
-            float4* o = reinterpret_cast<float4*>(hf8 + ((size_t)lane * rows_total + row) * 8);
-            o[0] = lane == 0 ? make_float4(acc[0], acc[1], acc[2], acc[3]) : make_float4(acc[4], acc[5], acc[6], acc[7]);
-            o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 4; ++i) r4[i] = (hi32 ? acc[4 + i] : acc[i]) + __shfl_xor(hi32 ? acc[i] : acc[4 + i], 32, 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r2[i] = (hi16 ? r4[2 + i] : r4[i]) + __shfl_xor(hi16 ? r4[i] : r4[2 + i], 16, 64);
+        float r = (hi8 ? r2[1] : r2[0]) + __shfl_xor(hi8 ? r2[0] : r2[1], 8, 64);
+        r += __shfl_xor(r, 4, 64);
+        r += __shfl_xor(r, 2, 64);
+        r += __shfl_xor(r, 1, 64);
+        // lanes 8g..8g+7 now hold sum number g = 4*hi32 + 2*hi16 + hi8 = (hand, class); hf8 row layout [hand][row][8]
+        if ((lane & 7) == 0) {
+            const int gsum = lane >> 3;
+            hf8[((size_t)(gsum >> 2) * rows_total + row) * 8 + (gsum & 3)] = r;
+        } else if ((lane & 7) == 4) {
+            const int gsum = lane >> 3;
+            hf8[((size_t)(gsum >> 2) * rows_total + row) * 8 + 4 + (gsum & 3)] = 0.f;
         }
     }
 }

@@ -1,6 +1,6 @@
 // MANO layer for gfx950: PCA pose -> Rodrigues -> shape/pose blend shapes -> kinematic chain ->
-// linear blend skinning -> 21 joints.  One 256-thread workgroup per (window, hand); the 16 joint
-// transforms live in LDS, threads stride over the 778 vertices, blend-shape matrix is stored
+// linear blend skinning -> 21 joints.  One 832-thread workgroup per (window, hand), a vertex per thread; the 16 joint
+// transforms live in LDS, the blend-shape matrix is stored
 // transposed ([145][2336]) so vertex reads are coalesced.
 //
 // Reference: /root/reference/src/Ev2Hands/model/utils.py:25-31 (SmplxAdapter.__call__) which calls
@@ -24,7 +24,9 @@ struct ManoP {
 __constant__ int c_parent[NJ] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
 __constant__ int c_joint_reorder[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
 
-__global__ __launch_bounds__(256) void mano_kernel(ManoP p) {
+constexpr int MANO_THREADS = 832;     // 13 waves: one vertex per thread (778), so the 145-term blend sums of a window run side by side
+
+__global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     __shared__ float s_pose[48];
     __shared__ float s_R[NJ][9];
     __shared__ float s_coef[NCOEF + 3];
@@ -126,15 +128,17 @@ __global__ __launch_bounds__(256) void mano_kernel(ManoP p) {
 
     // 7. blend shapes + skinning per vertex
     const float trx = transl[0], try_ = transl[1], trz = transl[2];
-    for (int v = tid; v < NV; v += 256) {
+    for (int v = tid; v < NV; v += MANO_THREADS) {
         float vp[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* col = p.c.blend_T + v * 3 + c;
             float s = 0.f;
+#pragma unroll
             for (int k = 0; k < NB; ++k) s = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], s);
             const float vs = __fadd_rn(s, p.c.v_template[v * 3 + c]);
             float q = 0.f;
+#pragma unroll 15
             for (int k = NB; k < NCOEF; ++k) q = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], q);
             vp[c] = __fadd_rn(vs, q);
         }
@@ -182,7 +186,7 @@ extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp
     EV2H_CHECK_ARG(c->ncomps >= 1 && c->ncomps <= 45 && ldp >= 3 + c->ncomps + 13);
     ManoP p{};
     p.c = *c; p.params = params; p.ldp = ldp; p.verts = verts; p.joints = joints;
-    mano_kernel<<<B, 256, 0, (hipStream_t)stream>>>(p);
+    mano_kernel<<<B, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -76,6 +76,15 @@ def bench_gemm(B=256, N=2048, precision="f32", rows=128):
         print(f"[{precision}/{rows}] gemm M={M} N={Nn} K={K}x{taps} {tag:8s}: {ms:8.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s ({flop / ms / 1e9 / 157.3 * 100:5.1f}%)")
 
 
+def bench_mano(B=256):
+    from ev2hands_amd import synth
+    from ev2hands_amd.mano import ManoHand
+    hand = ManoHand(synth.synth_mano_assets("right", 0), "cuda")
+    go, hp, be, tr = (torch.randn(B, n, device="cuda") * 0.3 for n in (3, 6, 10, 3))
+    ms = timeit(lambda: hand(go, hp, be, tr), iters=20)
+    print(f"mano layer B={B}: {ms * 1e3:8.1f} us per hand")
+
+
 def bench_events(B=256, n_ev=2500):
     import time
     import numpy as np
@@ -121,6 +130,8 @@ if __name__ == "__main__":
         bench_events()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("mano", "all"):
+        bench_mano()
     if what in ("gemmb", "all"):
         for prec in os.environ.get("KBENCH_PREC", "bf16x3,f16x2,bf16").split(","):
             bench_gemm(precision=prec, rows=128)
