@@ -45,7 +45,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="event windows per GPU per step")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
