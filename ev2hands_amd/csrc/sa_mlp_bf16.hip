@@ -54,8 +54,14 @@ struct SaBCfg {
     static constexpr int RS3 = NS * C2P * 2 + 16;                        // bytes per row of a W3 tile
     static constexpr int TB2 = T2 * 32 * RS2;
     static constexpr int TB3 = 32 * RS3;
-    static constexpr int TILE = ((TB2 > TB3 ? TB2 : TB3) + 1023) / 1024 * 1024;
-    static constexpr int LDS_BYTES = 2 * TILE + C1 * 16 + T2 * 32 * 4;
+    // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
+    // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
+    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4;
+    static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
+    static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
+    static constexpr int CPT = fits(2) ? 2 : 1, UPT = CPT;
+    static constexpr int TILE = tile_bytes(CPT, UPT);
+    static constexpr int LDS_BYTES = 2 * TILE + SMALL;
     // resident variant: every tile image of the module stays in LDS for the lifetime of the (persistent) workgroup
     static constexpr int RES_W = (NC1 * TB2 + T3 * TB3 + 1023) / 1024 * 1024;
     static constexpr int RES_LDS_BYTES = RES_W + C1 * 16 + T2 * 32 * 4;
@@ -101,8 +107,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                                                  (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
         }
     };
-    auto dma_w2 = [&](int c, char* dst) { dma_tile(p.W2s + (size_t)c * Cfg::TB2, dst, Cfg::TB2); };
-    auto dma_w3 = [&](int u, char* dst) { dma_tile(p.W3s + (size_t)u * Cfg::TB3, dst, Cfg::TB3); };
+    constexpr int CPT = RES ? 1 : Cfg::CPT, UPT = RES ? 1 : Cfg::UPT;
+    auto dma_w2 = [&](int step, char* dst) { dma_tile(p.W2s + (size_t)step * CPT * Cfg::TB2, dst, CPT * Cfg::TB2); };
+    auto dma_w3 = [&](int step, char* dst) { dma_tile(p.W3s + (size_t)step * UPT * Cfg::TB3, dst, UPT * Cfg::TB3); };
 
     int buf = 0;
     if constexpr (RES) {
@@ -165,9 +172,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll 1
         for (int c = 0; c < NC1; ++c) {
             STAMP(2 + 4 * c);
-            char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0);
+            char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0) + (c % CPT) * Cfg::TB2;
             char* nxt = buf ? wt0 : wt1;
-            if constexpr (!RES) { if (c + 1 < NC1) dma_w2(c + 1, nxt); else dma_w3(0, nxt); }
+            if constexpr (!RES) {
+                if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
+            }
             if (!Cfg::PREFETCH_P1 && c > 0) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
@@ -216,11 +225,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
             STAMP(4 + 4 * c);
             if constexpr (!RES) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued above has landed
-                __syncthreads();
+                if (c % CPT == CPT - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile DMA issued at the start of the step has landed
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
             STAMP(5 + 4 * c);
-            buf ^= 1;
         }
 
         STAMP(38);
@@ -242,11 +253,15 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll 1
         for (int u = 0; u < T3; ++u) {
             STAMP(40 + 4 * u);
-            char* cur = RES ? smem + NC1 * Cfg::TB2 + u * Cfg::TB3 : (buf ? wt1 : wt0);
+            char* cur = RES ? smem + NC1 * Cfg::TB2 + u * Cfg::TB3 : (buf ? wt1 : wt0) + (u % UPT) * Cfg::TB3;
             char* nxt = buf ? wt0 : wt1;
-            const bool more_w3 = (u + 1 < T3);
-            const bool more = more_w3 || (strip + 1 < nstrips);
-            if constexpr (!RES) { if (more_w3) dma_w3(u + 1, nxt); else if (more) dma_w2(0, nxt); }
+            if constexpr (!RES) {
+                if (u % UPT == 0) {
+                    const bool more_w3 = (u + UPT < T3);
+                    const bool more = more_w3 || (strip + 1 < nstrips);
+                    if (more_w3) dma_w3(u / UPT + 1, nxt); else if (more) dma_w2(0, nxt);
+                }
+            }
             // two accumulators take alternate plane products (see layer 2); their sum is the tile
             f32x16 acc, acc1;
 #pragma unroll
@@ -283,11 +298,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
             STAMP(42 + 4 * u);
             if constexpr (!RES) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
+                if (u % UPT == UPT - 1) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    buf ^= 1;
+                }
             }
             STAMP(43 + 4 * u);
-            buf ^= 1;
         }
         STAMP(37);
     }
