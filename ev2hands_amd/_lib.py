@@ -28,7 +28,7 @@ class SaDesc(C.Structure):
                 ("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("out", vp), ("ldo", ci),
                 ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("cnt_ld", ci)]
 
 
 class SaBranch(C.Structure):

@@ -240,7 +240,7 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
 
 // one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius
 static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
-                     int32_t* const* gidx, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st) {
+                     int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     ev2h_gemm_desc g{};
@@ -257,6 +257,8 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s;
+        static const bool no_skip = getenv("EV2H_SA_NO_SKIP") != nullptr;       // A/B switch: process padding strips too
+        d.cnt = (cnt && !no_skip) ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
         char t[40];
         snprintf(t, sizeof(t), "%s.%d", tag, i);
         prof_begin(t, st);
@@ -340,7 +342,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
-        RUN(sa_module(w->precision, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
+        RUN(sa_module(w->precision, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
     {
@@ -350,7 +352,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         int32_t* gi[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
         for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi, ws.i("cnt2"), st));
-        RUN(sa_module(w->precision, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
+        RUN(sa_module(w->precision, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
                                                                                    ws.f("l2buf"), 520, 512);
         EV2H_CHECK_LAUNCH();
@@ -396,7 +398,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         const char* const* nm = kHandNames[h];
         ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
-        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh));
+        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)sh>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
                                                                                    ws.f(nm[6]), 520, 512);
         EV2H_CHECK_LAUNCH();

@@ -28,6 +28,7 @@ struct SaBP {
     float* out; int ldo;
     int B, Npts, S, K;
     int nblk;
+    const int32_t* cnt; int cnt_ld;       // optional distinct-neighbour counts (ev2h_sa_desc.cnt)
     int per_xcd;                          // resident variant: groups per XCD (multiple of 8); nblk is a multiple of 8
 };
 
@@ -56,7 +57,7 @@ struct SaBCfg {
     static constexpr int TB3 = 32 * RS3;
     // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
     // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
-    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4;
+    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4 + 16;   // W1x, b2, one int for the workgroup's strip count
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
     static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
     static constexpr int CPT = fits(2) ? 2 : 1, UPT = CPT;
@@ -64,7 +65,7 @@ struct SaBCfg {
     static constexpr int LDS_BYTES = 2 * TILE + SMALL;
     // resident variant: every tile image of the module stays in LDS for the lifetime of the (persistent) workgroup
     static constexpr int RES_W = (NC1 * TB2 + T3 * TB3 + 1023) / 1024 * 1024;
-    static constexpr int RES_LDS_BYTES = RES_W + C1 * 16 + T2 * 32 * 4;
+    static constexpr int RES_LDS_BYTES = RES_W + C1 * 16 + T2 * 32 * 4 + 16;
     static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
 };
@@ -136,8 +137,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
 
     const float4 ctr = p.ctr4[gg];
-    const int nstrips = p.K >> 5;
     const int32_t* gi = p.gidx + (size_t)gg * p.K;
+    // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
+    // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
+    // workgroup's longest group (DMA pieces and barriers), without computing.
+    int my_strips = p.K >> 5;
+    if (p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
+    int nstrips = my_strips;
+    if constexpr (!RES) {
+        int* s_strips = reinterpret_cast<int*>(smem + WBYTES + C1 * 16 + T2 * 32 * 4);
+        if (tid == 0) *s_strips = 1;
+        __syncthreads();
+        if (lane == 0) atomicMax(s_strips, my_strips);
+        __syncthreads();
+        nstrips = *s_strips;
+    }
 
 #ifdef EV2H_SAB_TIMELINE
     const bool dbgw = (blockIdx.x == 300 && tid == 0);
@@ -145,6 +159,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #endif
     for (int strip = 0; strip < nstrips; ++strip) {
         STAMP(0);
+        if constexpr (!RES) {
+            if (strip >= my_strips) {           // wave-uniform: keep the workgroup's DMA / barrier sequence, no arithmetic
+                for (int c = 0; c < NC1; ++c) {
+                    char* nxt = buf ? wt0 : wt1;
+                    if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
+                    if (c % CPT == CPT - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); buf ^= 1; }
+                }
+                for (int u = 0; u < T3; ++u) {
+                    char* nxt = buf ? wt0 : wt1;
+                    if (u % UPT == 0) { if (u + UPT < T3) dma_w3(u / UPT + 1, nxt); else if (strip + 1 < nstrips) dma_w2(0, nxt); }
+                    if (u % UPT == UPT - 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); buf ^= 1; }
+                }
+                continue;
+            }
+        }
         const int idx = gi[strip * 32 + l31];
         const float4 q = p.pts4[(size_t)b * p.Npts + idx];
         const float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
@@ -377,6 +406,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.P1 = d->P1; p.ldp = d->ldp; p.pts4 = (const float4*)d->pts4; p.ctr4 = (const float4*)d->ctr4; p.gidx = d->gidx;
     p.W1x = (const float4*)d->W1x; p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
+    p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);

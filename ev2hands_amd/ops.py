@@ -112,9 +112,10 @@ def make_w_image(W: torch.Tensor, precision: str, rows: int = 128) -> torch.Tens
     return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), NS_OF[precision], rows)).to(W.device)
 
 
-def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32") -> torch.Tensor:
+def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None) -> torch.Tensor:
     """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3].
-    W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); bf16 tile images are built here when needed."""
+    W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); 16-bit tile images are built here when needed.
+    cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped."""
     B, Npts, C1 = P1.shape
     S, K = gidx.shape[1], gidx.shape[2]
     C3 = W3.shape[0]
@@ -125,6 +126,9 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     d.out, d.ldo = out.data_ptr(), C3
     d.B, d.Npts, d.S, d.K, d.C1, d.C2, d.C3 = B, Npts, S, K, C1, C2, C3
     d.precision = _lib.PREC[precision]
+    if cnt is not None:
+        assert cnt.dtype == torch.int32 and cnt.is_contiguous() and cnt.shape == (B, S)
+        d.cnt, d.cnt_ld = cnt.data_ptr(), 1
     keep = []
     if precision != "f32":
         from .pack import NS_OF, sa_bf16_images

@@ -127,6 +127,10 @@ typedef struct ev2h_sa_desc {
     int precision;               /* EV2H_PREC_*                                                         */
     const void* W2s;             /* bf16 tile images of W2 / W3 for BF16 / BF16X3 (ev2hands_amd/pack.py), */
     const void* W3s;             /* NULL for F32                                                        */
+    const int32_t* cnt;          /* optional: cnt[(b*S + s) * cnt_ld] = number of distinct neighbours of the group   */
+    int cnt_ld;                  /* (ev2h_ball_query's count output); slots >= cnt repeat slot 0, so whole 32-slot
+                                    strips of padding are skipped by the 16-bit kernels -- the max is unchanged.  NULL (or
+                                    EV2H_PREC_F32) = process all K slots                                       */
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 

@@ -187,6 +187,37 @@ def test_sa_mlp_max(C1, C2, C3, K, precision, tol):
     assert err < tol
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "bf16"])
+@pytest.mark.parametrize("C1,C2,C3,K", [(64, 96, 128, 128), (128, 196, 256, 128), (128, 128, 256, 64)])
+def test_sa_mlp_max_skips_padding_strips(C1, C2, C3, K, precision):
+    """query_ball_point pads the slots past a group's neighbour count with slot 0 (pointnet2_utils.py:104-106); given the
+    counts, the kernel skips 32-slot strips that hold only padding -- the output must not change by a single bit."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    B, Npts, S = 2, 512, 43
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, C1 + C2 + 1) * sc).float()
+    P1 = g("P1", (B, Npts, C1))
+    xyz = cloud_xyz("U", B, Npts, 43)
+    ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), C3 + 1)).int()
+    cnt = torch.from_numpy(synth.hash_randint("cnt", 1, K + 1, (B, S), 5)).int()
+    cnt[0, :8] = K                                   # one workgroup of full groups, one group with a single neighbour
+    cnt[1, 3] = 1
+    slot = torch.arange(K).view(1, 1, K)
+    gidx = torch.where(slot < cnt.unsqueeze(-1), gidx, gidx[:, :, :1]).contiguous()
+    up = lambda x, m: (x + m - 1) // m * m
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = g("W1x", (C1, 3), 0.5)
+    W2p = torch.zeros(up(C2, 32), C1); W2p[:C2] = g("W2", (C2, C1), C1 ** -0.5)
+    b2p = torch.zeros(up(C2, 32)); b2p[:C2] = g("b2", (C2,), 0.1)
+    W3p = torch.zeros(C3, up(C2, 8)); W3p[:, :C2] = g("W3", (C3, C2), C2 ** -0.5)
+    b3 = g("b3", (C3,), 0.1)
+    args = (P1.cuda(), ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2p.cuda(), b2p.cuda(),
+            W3p.cuda(), b3.cuda(), C2, precision)
+    full = ops.sa_mlp_max(*args)
+    skipped = ops.sa_mlp_max(*args, cnt=cnt.cuda())
+    assert torch.equal(full, skipped)
+
+
 def test_attention():
     _need_gpu()
     from ev2hands_amd import ops

@@ -1,0 +1,20 @@
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from ev2hands_amd import synth
+from ev2hands_amd.model import TEHNetWrapper
+B, C, N = 256, 4, 2048
+os.environ["ERPC"] = "0"; os.environ["EV2H_PRECISION"] = "f16x2"
+assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
+for kind in ("E", "U"):
+    net = TEHNetWrapper("cuda:0", mano_assets=assets); net.load_state_dict(synth.synth_state_dict(C, 0), strict=True); net.eval()
+    xyz = synth.synth_cloud(kind, B, C, N, 1000).cuda()
+    net.net.fps_init = synth.fps_inits(B, N, 7)
+    with torch.no_grad(): net(xyz)
+    torch.cuda.synchronize()
+    for name, nrad, Ks, w in (("cnt1", 3, (32, 64, 128), (0.17, 0.92, 2.25)), ("cnt2", 2, (64, 128), (0.69, 1.8)), ("cntmL", 2, (64, 128), (0.69, 1.8)), ("cntmR", 2, (64, 128), (0.69, 1.8))):
+        c = net.net.debug_buffer(name, torch.int32).view(-1, nrad).float()
+        out = []
+        for i, K in enumerate(Ks):
+            strips = torch.clamp(torch.ceil(c[:, i] / 32), min=1)
+            out.append(f"K={K}: saturated {float((c[:, i] >= K).float().mean())*100:.0f}%, live strips {float(strips.mean())/(K/32)*100:.0f}%")
+        print(kind, name, "; ".join(out))
