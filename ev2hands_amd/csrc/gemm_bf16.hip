@@ -1,8 +1,8 @@
-// Dense layers on the bf16 matrix pipe: same contract as gemm.hip (ev2h_gemm), operands split on the fly.
-//   NS = 3 "bf16x3": X and W tiles are split exactly into three bf16 planes while they are staged into LDS
-//          (x = h + m + l, truncation split) and the 6 plane products hh, hm, mh, mm, hl, lh are accumulated
-//          in fp32 by v_mfma_f32_32x32x16_bf16 -- fp32-class accuracy at 6/16 of the fp32 MFMA cost;
-//   NS = 1 plain bf16 (RNE) operands, fp32 accumulate.
+// Dense layers on the 16-bit matrix pipe: same contract as gemm.hip (ev2h_gemm), operands split on the fly into the
+// NS planes of planes.hpp (NS = 2 "f16x2", NS = 3 "bf16x3": fp32-class; NS = 1 plain bf16), fp32 accumulate.
+// Three kernels: a generic one that splits both operands (W without a plane image: the tiny heads), a wide 128x256
+// one and the default 128x128 "occupancy" kernel, both with host-packed W plane images streamed by LDS-DMA.
+// First kernel:
 // 128x128x32 tiles, 8 waves (2 x 4), each wave 64 x 32 outputs (2 accumulator tiles); LDS rows hold the
 // NS planes side by side (NS*64 B + 16 B pad => conflict-free ds_read_b128); register prefetch of the
 // next K tile, two LDS buffers, one barrier per K tile.

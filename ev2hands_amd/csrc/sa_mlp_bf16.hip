@@ -9,7 +9,8 @@
 //
 // Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
 // ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
-// (global_load_lds_dwordx4, no staging registers); two buffers, one barrier per tile.
+// (global_load_lds_dwordx4, no staging registers): two buffers and one barrier per tile step (one or two tiles) in the
+// streamed variant; the narrow MLPs keep all tiles resident in a persistent workgroup (see the kernel's comment).
 #include <algorithm>
 #include <cstdlib>
 #include "planes.hpp"
