@@ -131,9 +131,15 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EV2H_BENCH_FORCE_DIST=1 runs the RCCL code path (init, all-gather, barrier, all-reduce) with a single rank, e.g.
+    # under `torchrun --nproc-per-node 1`, to check it on a one-GPU box
+    use_dist = world > 1 or bool(os.environ.get("EV2H_BENCH_FORCE_DIST"))
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     from ev2hands_amd.model import TEHNetWrapper
 
@@ -162,12 +168,12 @@ def main():
         net.net.fps_init = inits
         with torch.no_grad():
             out = net(xyz)
-        if world > 1:
+        if use_dist:
             out = evdist.all_gather_outputs(out, N)
         return out
 
     def sync():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -180,7 +186,7 @@ def main():
         sync()
         dt_ = time.perf_counter() - t0
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
@@ -240,7 +246,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
