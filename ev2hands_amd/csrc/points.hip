@@ -121,12 +121,14 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
     for (int p = tid; p < N; p += 256) spts[p] = src[p];
     __syncthreads();
 
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int s_begin = blockIdx.x * BALL_CTR_PER_WG;
     for (int s = s_begin + wave; s < s_begin + BALL_CTR_PER_WG && s < S; s += 4) {
         const float4 c = ctr4[(size_t)b * S + s];
         int cnt[3] = {0, 0, 0};
         int first[3] = {0, 0, 0};
+        int32_t* gbase[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gbase[i] = (i < a.nrad) ? a.gidx[i] + ((size_t)b * S + s) * a.K[i] : nullptr;
         for (int base = 0; base < N; base += 64) {
             const int p = base + lane;
             const float4 q = spts[p < N ? p : N - 1];
@@ -136,12 +138,13 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
             bool done = true;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                if (i < a.nrad) {
+                if (i < a.nrad && cnt[i] < a.K[i]) {       // wave-uniform: a radius whose K slots are full costs nothing more
                     const bool in = (p < N) && !(d > a.r2[i]);
                     const unsigned long long m = __ballot(in);
                     if (cnt[i] == 0 && m != 0ull) first[i] = base + __ffsll((long long)m) - 1;
-                    const int pos = cnt[i] + __popcll(m & lt_mask);
-                    if (in && pos < a.K[i]) a.gidx[i][((size_t)b * S + s) * a.K[i] + pos] = p;
+                    // slot = neighbours found so far + set bits below this lane (v_mbcnt)
+                    const int pos = cnt[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (in && pos < a.K[i]) gbase[i][pos] = p;
                     cnt[i] += __popcll(m);
                     done = done && (cnt[i] >= a.K[i]);
                 }
