@@ -1,0 +1,179 @@
+// Two-hand mesh self-collision on the GPU, the per-frame consumer of the predicted vertices:
+//   /root/reference/src/Ev2Hands/evaluate_ev2hands_r.py:128-160  compute_non_collision_score
+//   /root/reference/src/Ev2Hands/utils/__init__.py:106-124       compute_collision_percentage
+// The reference hands `vertices[faces]` of the concatenated left+right mesh (float32 metres * 1000, widened to float64) to
+// the BVH of the un-vendored torch-mesh-isect package and counts the returned triangle pairs.  That package's arithmetic
+// is not available (parity unpinned, see oracle/collision_oracle.py); this kernel computes the quantity the tree
+// approximates: ALL unordered pairs of triangles that share no vertex index and intersect (separating-axis test in
+// float64), in lexicographic order, no per-triangle cap.
+//
+// 3 076 triangles per window are 4.7 M pairs: no tree is needed.  One 1024-thread workgroup per window keeps the window's
+// vertices (float32, exact), faces and float32 bounding boxes in LDS (142 KB); each wave owns 64-row blocks of the pair
+// matrix and walks the columns j uniformly, so box j and face j are LDS broadcasts; only box-overlapping, non-adjacent
+// candidates (a few per row) reach the float64 test.  Two passes (count, prefix sum over the rows, write) make the
+// pair list deterministic.
+#include "common.hpp"
+#include "ev2hands_hip.h"
+
+namespace {
+
+constexpr int COL_MAX_V = 778, COL_MAX_F = 1538, COL_THREADS = 1024;
+
+struct ColP {
+    const float* vl; const float* vr;          // [B][nv][3] metres
+    const int32_t* fl; const int32_t* fr;      // [nf][3]
+    int nv, nf;
+    float scale;
+    int max_pairs;
+    int32_t* pairs;                            // [B][max_pairs][2] or null
+    int32_t* counts;                           // [B]
+};
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// true when `ax` separates the triangles (projections strictly disjoint); degenerate axes never separate
+__device__ __forceinline__ bool separated(const V3 (&a)[3], const V3 (&b)[3], V3 ax) {
+    if (dot(ax, ax) < 1e-20) return false;
+    const double a0 = dot(a[0], ax), a1 = dot(a[1], ax), a2 = dot(a[2], ax);
+    const double b0 = dot(b[0], ax), b1 = dot(b[1], ax), b2 = dot(b[2], ax);
+    const double amin = fmin(a0, fmin(a1, a2)), amax = fmax(a0, fmax(a1, a2));
+    const double bmin = fmin(b0, fmin(b1, b2)), bmax = fmax(b0, fmax(b1, b2));
+    return amax < bmin || bmax < amin;
+}
+
+__device__ bool sat_intersect(const V3 (&a)[3], const V3 (&b)[3]) {
+    const V3 ea[3] = {sub(a[1], a[0]), sub(a[2], a[1]), sub(a[0], a[2])};
+    const V3 eb[3] = {sub(b[1], b[0]), sub(b[2], b[1]), sub(b[0], b[2])};
+    const V3 na = cross(ea[0], ea[1]), nb = cross(eb[0], eb[1]);
+    if (separated(a, b, na) || separated(a, b, nb)) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (separated(a, b, cross(ea[i], eb[j]))) return false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (separated(a, b, cross(na, ea[i])) || separated(a, b, cross(nb, eb[i]))) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int V2 = 2 * p.nv, F2 = 2 * p.nf;
+    float* sv = reinterpret_cast<float*>(smem);                 // [V2][3] mm
+    int* sf = reinterpret_cast<int*>(sv + 3 * V2);              // [F2][3]
+    float* sbb = reinterpret_cast<float*>(sf + 3 * F2);         // [F2][6] min xyz, max xyz
+    int* srow = reinterpret_cast<int*>(sbb + 6 * F2);           // [F2 + 1] pairs per row, then exclusive prefix
+    int* spart = srow + F2 + 1;                                 // [COL_THREADS] scan scratch
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < 3 * V2; i += COL_THREADS) {
+        const int v = i / 3, c = i - 3 * v;
+        const float x = v < p.nv ? p.vl[((size_t)b * p.nv + v) * 3 + c] : p.vr[((size_t)b * p.nv + (v - p.nv)) * 3 + c];
+        sv[i] = __fmul_rn(x, p.scale);                          // float32 multiply like `.numpy() * 1000`
+    }
+    for (int i = tid; i < 3 * F2; i += COL_THREADS) {
+        const int f = i / 3, c = i - 3 * f;
+        sf[i] = f < p.nf ? p.fl[f * 3 + c] : p.fr[(f - p.nf) * 3 + c] + p.nv;
+    }
+    __syncthreads();
+    for (int f = tid; f < F2; f += COL_THREADS) {
+        float lo[3], hi[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float x0 = sv[3 * sf[3 * f] + c], x1 = sv[3 * sf[3 * f + 1] + c], x2 = sv[3 * sf[3 * f + 2] + c];
+            lo[c] = fminf(x0, fminf(x1, x2));
+            hi[c] = fmaxf(x0, fmaxf(x1, x2));
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sbb[6 * f + c] = lo[c]; sbb[6 * f + 3 + c] = hi[c]; }
+    }
+    __syncthreads();
+
+    auto tri = [&](const int (&f)[3], V3 (&t)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = {(double)sv[3 * f[k]], (double)sv[3 * f[k] + 1], (double)sv[3 * f[k] + 2]};
+    };
+    const int nblk = (F2 + 63) >> 6, nwaves = COL_THREADS >> 6;
+    int32_t* out = p.pairs ? p.pairs + (size_t)b * p.max_pairs * 2 : nullptr;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int rb = wave; rb < nblk; rb += nwaves) {
+            const int i = rb * 64 + lane;
+            const bool valid = i < F2;
+            const int ii = valid ? i : F2 - 1;
+            float lo[3], hi[3];
+            int fi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { lo[c] = sbb[6 * ii + c]; hi[c] = sbb[6 * ii + 3 + c]; fi[c] = sf[3 * ii + c]; }
+            int cnt = 0;
+            const int base = pass ? srow[ii] : 0;
+            for (int j = rb * 64 + 1; j < F2; ++j) {            // wave-uniform column: LDS broadcasts
+                const float* bj = sbb + 6 * j;
+                const bool ov = valid && j > i && lo[0] <= bj[3] && bj[0] <= hi[0] && lo[1] <= bj[4] && bj[1] <= hi[1] &&
+                                lo[2] <= bj[5] && bj[2] <= hi[2];
+                if (ov) {
+                    const int fj[3] = {sf[3 * j], sf[3 * j + 1], sf[3 * j + 2]};
+                    bool share = false;
+#pragma unroll
+                    for (int x = 0; x < 3; ++x)
+#pragma unroll
+                        for (int y = 0; y < 3; ++y) share = share || (fi[x] == fj[y]);
+                    if (!share) {
+                        V3 ta[3], tb[3];
+                        tri(fi, ta);
+                        tri(fj, tb);
+                        if (sat_intersect(ta, tb)) {
+                            if (pass && out && base + cnt < p.max_pairs) { out[2 * (base + cnt)] = i; out[2 * (base + cnt) + 1] = j; }
+                            ++cnt;
+                        }
+                    }
+                }
+            }
+            if (!pass && valid) srow[i] = cnt;
+        }
+        if (pass) break;
+        __syncthreads();
+        // exclusive prefix sum of srow[0..F2): each thread sums a contiguous chunk, Hillis-Steele over the chunk totals
+        const int per = (F2 + COL_THREADS - 1) / COL_THREADS;
+        const int lo_r = min(tid * per, F2), hi_r = min(lo_r + per, F2);
+        int s = 0;
+        for (int r = lo_r; r < hi_r; ++r) s += srow[r];
+        spart[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < COL_THREADS; o <<= 1) {
+            const int add = tid >= o ? spart[tid - o] : 0;
+            __syncthreads();
+            spart[tid] += add;
+            __syncthreads();
+        }
+        int run = spart[tid] - s;
+        for (int r = lo_r; r < hi_r; ++r) { const int c = srow[r]; srow[r] = run; run += c; }
+        if (tid == COL_THREADS - 1) p.counts[b] = spart[tid];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left,
+                                    const int32_t* faces_right, int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs,
+                                    int32_t* counts, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(verts_left && verts_right && faces_left && faces_right && counts);
+    EV2H_CHECK_ARG(B > 0 && nv >= 3 && nv <= COL_MAX_V && nf >= 1 && nf <= COL_MAX_F && max_pairs >= 0 && (pairs || max_pairs == 0));
+    ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts};
+    const size_t lds = (size_t)(3 * 2 * nv) * 4 + (size_t)(3 * 2 * nf) * 4 + (size_t)(6 * 2 * nf) * 4 + (size_t)(2 * nf + 1) * 4 +
+                       COL_THREADS * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+        attr_set = true;
+    }
+    mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}

@@ -180,6 +180,16 @@ int ev2h_joint_metrics(const float* j3d_left, const float* j3d_right, const doub
                        double dist_max_mm, float* pck, double* auc, double* mpjpe, double* root_distance, int32_t* best,
                        ev2h_stream_t stream);
 
+/* ---- two-hand mesh self-collision (next row 8f-4; evaluate_ev2hands_r.py:128-160, utils/__init__.py:106-124) ---------------- */
+/* verts_left / verts_right [B][nv][3] float32 metres (the forward's vertices), faces [nf][3] int32 (nv <= 778, nf <= 1538).
+ * The meshes are concatenated as the reference does (left faces, then right faces + nv), vertices scaled by `scale` (1000:
+ * mm) in float32 and tested in float64.  counts [B] = number of unordered triangle pairs that share no vertex index and
+ * intersect (separating-axis test, touching counts); pairs [B][max_pairs][2] (optional) = the first max_pairs of them in
+ * lexicographic (i < j) order.  The reference obtains its pairs from the un-vendored torch-mesh-isect BVH with a
+ * per-triangle candidate cap; this is the uncapped quantity (parity unpinned, oracle/collision_oracle.py). */
+int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left, const int32_t* faces_right,
+                         int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs, int32_t* counts, ev2h_stream_t stream);
+
 /* ---- whole path -------------------------------------------------------------------------------------- */
 typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;

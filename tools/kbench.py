@@ -85,6 +85,25 @@ def bench_mano(B=256):
     print(f"mano layer B={B}: {ms * 1e3:8.1f} us per hand")
 
 
+def bench_collision(B=256):
+    import time
+    import numpy as np
+    from ev2hands_amd.collision import mesh_collisions
+    from oracle import collision_oracle as CO
+    v, f = CO.icosphere(3)                       # 642 vertices, 1280 faces per "hand"
+    rng = np.random.default_rng(0)
+    vl = np.stack([(v * 0.04).astype(np.float32)] * B)
+    vr = np.stack([(v * 0.04 + np.array([0.03 + 0.04 * rng.random(), 0.01 * rng.normal(), 0.01 * rng.normal()])).astype(np.float32) for _ in range(B)])
+    a, b = torch.from_numpy(vl).cuda(), torch.from_numpy(vr).cuda()
+    ms = timeit(lambda: mesh_collisions(a, b, f, f), iters=5)
+    t0 = time.time()
+    verts, faces = CO.build_triangles(vl[0], vr[0], f, f)
+    n = CO.collision_pairs(verts, faces).shape[0]
+    cpu = time.time() - t0
+    print(f"mesh collisions B={B}, 2x{f.shape[0]} triangles: {ms:8.3f} ms on the GPU = {B / ms * 1e3:9.0f} windows/s; NumPy oracle {cpu * 1e3:7.1f} ms "
+          f"per window ({n} pairs in window 0)")
+
+
 def bench_events(B=256, n_ev=2500):
     import time
     import numpy as np
@@ -130,6 +149,8 @@ if __name__ == "__main__":
         bench_events()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("collision", "all"):
+        bench_collision()
     if what in ("mano", "all"):
         bench_mano()
     if what in ("gemmb", "all"):
