@@ -35,6 +35,7 @@ CASES = [
     ("E_c5_n2048", "E", 5, 2048, 2, 1),
     ("U_c5_n256", "U", 5, 256, 2, 2),
     ("E_c4_n256", "E", 4, 256, 2, 3),
+    ("E_c4_n8192", "E", 4, 8192, 1, 4),      # BASELINE.json config 5 window size
 ]
 
 
@@ -181,8 +182,10 @@ def run_case(pn, te, name, kind, C, N, B, seed):
 def main():
     torch.set_num_threads(8)
     pn, te = load_reference()
+    only = sys.argv[1:]                      # optional: names of the cases to (re)generate
     for case in CASES:
-        run_case(pn, te, *case)
+        if not only or case[0] in only:
+            run_case(pn, te, *case)
 
 
 if __name__ == "__main__":
