@@ -64,6 +64,28 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
+// wave-wide unsigned max with DPP row shifts / row broadcasts (6 short-latency steps instead of 6 ds_bpermute round trips);
+// result broadcast from lane 63
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v) {
+#define EV2H_DPP_MAX(ctrl, rmask) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false))
+    EV2H_DPP_MAX(0x111, 0xf);      // row_shr:1
+    EV2H_DPP_MAX(0x112, 0xf);      // row_shr:2
+    EV2H_DPP_MAX(0x114, 0xf);      // row_shr:4
+    EV2H_DPP_MAX(0x118, 0xf);      // row_shr:8   -> lane 15 of every 16-lane row holds the row's max
+    EV2H_DPP_MAX(0x142, 0xa);      // row_bcast:15 into rows 1 and 3
+    EV2H_DPP_MAX(0x143, 0xc);      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+#undef EV2H_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// max of (hi, lo) pairs ordered by hi, then lo: two 32-bit DPP reductions
+__device__ __forceinline__ unsigned long long wave_max_u64_dpp(unsigned long long v) {
+    const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+    const unsigned mhi = wave_max_u32_dpp(hi);
+    const unsigned mlo = wave_max_u32_dpp(hi == mhi ? lo : 0u);
+    return ((unsigned long long)mhi << 32) | mlo;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {

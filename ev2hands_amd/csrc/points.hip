@@ -11,6 +11,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float sqnorm3(float x, float y, float z) {
     return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
 }
@@ -78,18 +80,37 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
         const float4 c = spts[far];
         if (tid == 0) { oidx[i] = far; octr[i] = c; }
         unsigned long long best = 0ull;
+        if constexpr (PPT >= 2) {
+            // two points per packed fp32 instruction (v_pk_add_f32 / v_pk_mul_f32: same IEEE results, half the issue slots);
+            // the kernel is VALU-throughput bound (three workgroups share a CU), so this is where the time goes
+            const f32x2 cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int p = j * 256 + tid;
-            const float dx = __fsub_rn(px[j], c.x), dy = __fsub_rn(py[j], c.y), dz = __fsub_rn(pz[j], c.z);
-            const float d = sqnorm3(dx, dy, dz);
-            if (d < md[j]) md[j] = d;
-            // key: larger distance first, then smaller index (torch.max returns the first maximum)
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(md[j]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
-            if (p < N && key > best) best = key;
+            for (int j = 0; j < PPT; j += 2) {
+                const f32x2 dx = f32x2{px[j], px[j + 1]} - cx, dy = f32x2{py[j], py[j + 1]} - cy, dz = f32x2{pz[j], pz[j + 1]} - cz;
+                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int p = (j + e) * 256 + tid;
+                    if (d[e] < md[j + e]) md[j + e] = d[e];
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(md[j + e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
+                    if (p < N && key > best) best = key;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const int p = j * 256 + tid;
+                const float dx = __fsub_rn(px[j], c.x), dy = __fsub_rn(py[j], c.y), dz = __fsub_rn(pz[j], c.z);
+                const float d = sqnorm3(dx, dy, dz);
+                if (d < md[j]) md[j] = d;
+                // key: larger distance first, then smaller index (torch.max returns the first maximum)
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(md[j]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
+                if (p < N && key > best) best = key;
+            }
         }
-        best = wave_max_u64(best);
+        best = wave_max_u64_dpp(best);
         if (lane == 0) skey[i & 1][wave] = best;
         __syncthreads();
         unsigned long long k0 = skey[i & 1][0], k1 = skey[i & 1][1], k2 = skey[i & 1][2], k3 = skey[i & 1][3];
