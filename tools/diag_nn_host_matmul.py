@@ -1,3 +1,5 @@
+"""Diagnostic (kept for reference): how the host's torch-CPU evaluates the K=3 matmul in square_distance (fma chain), the fact the
+3-NN / ball-query parity rests on.  Imports oracle/, so it is test tooling, not product code."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np, subprocess
