@@ -130,7 +130,7 @@ struct BallArgs {
     int32_t* cnt;   // [B][S][nrad] (may be null)
 };
 
-constexpr int BALL_CTR_PER_WG = 32;
+constexpr int BALL_CTR_PER_WG = 32, BALL_UNR = 4;
 
 __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restrict__ pts4, const float4* __restrict__ ctr4,
                                                          int N, int S, BallArgs a) {
@@ -150,23 +150,33 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
         int32_t* gbase[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) gbase[i] = (i < a.nrad) ? a.gidx[i] + ((size_t)b * S + s) * a.K[i] : nullptr;
-        for (int base = 0; base < N; base += 64) {
-            const int p = base + lane;
-            const float4 q = spts[p < N ? p : N - 1];
-            // square_distance (pointnet2_utils.py:37-39): -2*(c.q) + |c|^2 + |q|^2, dot as an fma chain
-            const float dot = __fmaf_rn(c.z, q.z, __fmaf_rn(c.y, q.y, __fmul_rn(c.x, q.x)));
-            const float d = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), c.w), q.w);
+        // BALL_UNR chunks of 64 points per step: the distance evaluations and LDS reads of a step are independent, the
+        // scalar bookkeeping (counts, exit test) is paid once per step; slots are still filled in ascending point order
+        for (int base = 0; base < N; base += 64 * BALL_UNR) {
+            float d[BALL_UNR];
+#pragma unroll
+            for (int u = 0; u < BALL_UNR; ++u) {
+                const int p = base + 64 * u + lane;
+                const float4 q = spts[p < N ? p : N - 1];
+                // square_distance (pointnet2_utils.py:37-39): -2*(c.q) + |c|^2 + |q|^2, dot as an fma chain
+                const float dot = __fmaf_rn(c.z, q.z, __fmaf_rn(c.y, q.y, __fmul_rn(c.x, q.x)));
+                d[u] = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), c.w), q.w);
+            }
             bool done = true;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 if (i < a.nrad && cnt[i] < a.K[i]) {       // wave-uniform: a radius whose K slots are full costs nothing more
-                    const bool in = (p < N) && !(d > a.r2[i]);
-                    const unsigned long long m = __ballot(in);
-                    if (cnt[i] == 0 && m != 0ull) first[i] = base + __ffsll((long long)m) - 1;
-                    // slot = neighbours found so far + set bits below this lane (v_mbcnt)
-                    const int pos = cnt[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (in && pos < a.K[i]) gbase[i][pos] = p;
-                    cnt[i] += __popcll(m);
+#pragma unroll
+                    for (int u = 0; u < BALL_UNR; ++u) {
+                        const int p = base + 64 * u + lane;
+                        const bool in = (p < N) && !(d[u] > a.r2[i]);
+                        const unsigned long long m = __ballot(in);
+                        if (cnt[i] == 0 && m != 0ull) first[i] = base + 64 * u + __ffsll((long long)m) - 1;
+                        // slot = neighbours found so far + set bits below this lane (v_mbcnt)
+                        const int pos = cnt[i] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (in && pos < a.K[i]) gbase[i][pos] = p;
+                        cnt[i] += __popcll(m);
+                    }
                     done = done && (cnt[i] >= a.K[i]);
                 }
             }
