@@ -1,0 +1,18 @@
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+from ev2hands_amd import synth
+from ev2hands_amd.model import TEHNetWrapper
+os.environ["ERPC"]="0"; os.environ["EV2H_PRECISION"]="f16x2"
+assets = {s: synth.synth_mano_assets(s, 0) for s in ("left","right")}
+net = TEHNetWrapper("cuda:0", mano_assets=assets); net.load_state_dict(synth.synth_state_dict(4,0), strict=True); net.eval()
+xyz = synth.synth_cloud("E", 256, 4, 2048, 1).cuda(); inits = synth.fps_inits(256, 2048, 7)
+for _ in range(3):
+    net.net.fps_init = inits
+    with torch.no_grad(): net(xyz)
+torch.cuda.synchronize()
+t0=time.perf_counter(); n=20
+for _ in range(n):
+    net.net.fps_init = inits
+    with torch.no_grad(): o = net(xyz)
+t1=time.perf_counter(); torch.cuda.synchronize(); t2=time.perf_counter()
+print(f"host enqueue {1e3*(t1-t0)/n:.2f} ms/step, total {1e3*(t2-t0)/n:.2f} ms/step")
