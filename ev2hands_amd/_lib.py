@@ -125,7 +125,7 @@ def lib() -> C.CDLL:
     mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs)]
     if list(sizes) != mine:
         raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
-    if L.ev2h_abi_version() != 1:
+    if L.ev2h_abi_version() != 2:      # 2: f16x2 precision, ev2h_sa_desc.cnt, ev2h_mesh_collisions
         raise Ev2hError("ABI version mismatch")
     _lib = L
     return L

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 1
+#define EV2H_ABI_VERSION 2
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
