@@ -93,7 +93,8 @@ class TEHNet(nn.Module):
         self.left_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.right_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.mhlnes = int(os.getenv("MHLNES", 0))
-        # arithmetic of the MFMA contractions: "f32" (exact), "bf16x3" (fp32-class, 3-plane split), "bf16"
+        # arithmetic of the matrix contractions: "f32" (exact fp32 MFMA, default here), "f16x2" / "bf16x3"
+        # (fp32-class split arithmetic on the 16-bit MFMA; f16x2 needs |values| < 65504), "bf16" (reduced precision)
         self.precision = os.getenv("EV2H_PRECISION", "f32")
         self.left_query_conv = _query_conv()
         self.right_query_conv = _query_conv()
@@ -207,8 +208,10 @@ class TEHNetWrapper:
     """model.py:10-64.  `mano_assets` / `mano_path` say where the MANO constants come from (the
     reference reads settings.MANO_PATH, which cannot be imported without pyrender)."""
 
-    def __init__(self, device, mano_path="../data/models", mano_assets=None):
+    def __init__(self, device, mano_path="../data/models", mano_assets=None, precision=None):
         self.net = TEHNet(n_pose_params=synth.MANO_CMPS).to(device)
+        if precision is not None:           # otherwise EV2H_PRECISION, default "f32"
+            self.net.precision = precision
         self.net.eval()
         self.training = False
         self.hands = create_mano_layers(mano_path, device, synth.MANO_CMPS, assets=mano_assets)
