@@ -261,3 +261,39 @@ def test_full_size_batch_properties(precision):
         agree = float((a["l"].argmax(1) == r["class_logits"].argmax(1)).float().mean())
         print(f"{precision} vs f32 at B=64: logits rel {rel(a['l'], r['class_logits']):.2e}, argmax agreement {agree * 100:.4f} %")
         assert agree == 1.0
+
+
+def test_two_stream_fork_is_bit_identical(tmp_path):
+    """EV2H_TWO_STREAMS=1 (opt-in: right-hand regressor and the MANO ball queries on a second stream) must not change a bit.
+    The switch is read once per process, so the forked run happens in a child process."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import os, sys, torch\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "from ev2hands_amd import synth\n"
+        "from ev2hands_amd.model import TEHNetWrapper\n"
+        "os.environ['ERPC'] = '0'\n"
+        "assets = {s: synth.synth_mano_assets(s, 3) for s in ('left', 'right')}\n"
+        "net = TEHNetWrapper('cuda:0', mano_assets=assets, precision='f16x2')\n"
+        "net.load_state_dict(synth.synth_state_dict(4, 3), strict=True); net.eval()\n"
+        "xyz = synth.synth_cloud('E', 6, 4, 2048, 3).cuda()\n"
+        "outs = []\n"
+        "for _ in range(3):\n"
+        "    net.net.fps_init = synth.fps_inits(6, 2048, 3)\n"
+        "    with torch.no_grad():\n"
+        "        o = net(xyz)\n"
+        "    outs.append(torch.cat([o['class_logits'].flatten(), o['left']['vertices'].flatten(), o['right']['vertices'].flatten(),\n"
+        "                           o['left']['j3d'].flatten(), o['right']['betas'].flatten()]).cpu())\n"
+        "assert all(torch.equal(outs[0], x) for x in outs[1:])\n"
+        "torch.save(outs[0], sys.argv[1])\n")
+    res = {}
+    for fork in ("0", "1"):
+        env = dict(os.environ, EV2H_TWO_STREAMS=fork)
+        out = tmp_path / f"out{fork}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[fork] = torch.load(out)
+    assert torch.equal(res["0"], res["1"])
