@@ -35,9 +35,10 @@ DTYPE = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
          "bf16x3": "f32 (each f32 operand split exactly into 3 bf16 planes, 6 plane products per MAC on the bf16 MFMA, f32 accumulate)",
          "f16x2": "f32 (each f32 operand split into 2 fp16 planes, 3 plane products per MAC on the f16 MFMA, f32 accumulate)",
          "bf16": "bf16 (f32 accumulate)"}
-# algorithmic work of the profiled kernel per window: layers 2+3 of mano.sa1 branch 1
+# algorithmic work of the profiled kernel per window: layers 2+3 of enc.sa2 branch 1 (same MLP and group shape as mano.sa1 branch 1;
+# launched before the two-hand stream fork, so its HIP-event duration is free of overlap)
 # (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
-PROFILED_TAG = "manoR.1"
+PROFILED_TAG = "sa2.1"
 PROFILED_MAC_PER_WINDOW = 128 * 128 * (128 * 196 + 196 * 256)
 
 

@@ -76,19 +76,20 @@ static inline void prof_end(const char* tag, ev2h_stream_t st) {
 
 // ---------------------------------------------------------------------------------------- side stream
 // The two MANO regressors are independent after the attention block, and their ball queries depend only on the
-// sampled centroids.  They are forked onto one library-owned side stream (fork/join with events, hipGraph-capturable),
-// so the small kernels of one hand (ball query, table GEMM, head GEMMs, MANO) overlap the MFMA-heavy kernels of the
-// other and fill their tails.  Measured gain at B=256: 0.6 % (both hands' big kernels fill the chip on their own), so the
-// fork is OPT-IN (EV2H_TWO_STREAMS=1); it also keeps the per-kernel event timing of bench.py free of overlap.
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-static int g_side_state = 0;   // 0 = not tried, 1 = ready, -1 = disabled
+// sampled centroids.  They are forked onto one library-owned side stream per host thread (fork/join with events,
+// hipGraph-capturable), so the small kernels of one hand (ball query, table GEMM, head GEMMs, MANO) overlap the
+// MFMA-heavy kernels of the other and fill their tails: +1.5-2 % windows/s at B=256, outputs bit-identical
+// (tests/test_gpu_forward.py::test_two_stream_fork_is_bit_identical).  EV2H_TWO_STREAMS=0 keeps everything on the caller's
+// stream.  Kernels of the two hands then overlap in time, so bench.py brackets a launch site before the fork (sa2.1).
+static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+static thread_local int g_side_state = 0;   // 0 = not tried, 1 = ready, -1 = disabled
 
 static bool side_ready() {
     if (g_side_state == 0) {
         const char* e = getenv("EV2H_TWO_STREAMS");
         g_side_state = -1;
-        if ((e && atoi(e) != 0) && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess) {
+        if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess) {
             bool ok = true;
             for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) == hipSuccess;
             if (ok) g_side_state = 1;

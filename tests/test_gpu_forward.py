@@ -291,7 +291,7 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
         "torch.save(outs[0], sys.argv[1])\n")
     res = {}
     for fork in ("0", "1"):
-        env = dict(os.environ, EV2H_TWO_STREAMS=fork)
+        env = dict(os.environ, EV2H_TWO_STREAMS=fork)      # "0" = single stream, "1" = forked (the default)
         out = tmp_path / f"out{fork}.pt"
         r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
