@@ -1,5 +1,7 @@
+"""Fill of the neighbour groups per set-abstraction module (share of saturated groups and of live 32-slot strips) on the
+bench clouds: what the padding-strip skip of the SA kernels can save.   python tools/group_fill.py"""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ev2hands_amd import synth
 from ev2hands_amd.model import TEHNetWrapper
 B, C, N = 256, 4, 2048

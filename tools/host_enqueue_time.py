@@ -1,5 +1,6 @@
+"""Host-side cost of one forward (Python wrapper + ~190 kernel launches) against the GPU time per step.   python tools/host_enqueue_time.py"""
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ev2hands_amd import synth
 from ev2hands_amd.model import TEHNetWrapper
 os.environ["ERPC"]="0"; os.environ["EV2H_PRECISION"]="f16x2"
