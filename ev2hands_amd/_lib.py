@@ -20,7 +20,7 @@ class GemmDesc(C.Structure):
                 ("M", ci), ("N", ci), ("K", ci),
                 ("bias", vp), ("bias_group_rows", ci), ("ldbias", ci), ("relu", ci),
                 ("post_scale", vp), ("post_shift", vp),
-                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci)]
+                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci), ("w_unscale", C.c_float)]
 
 
 class SaDesc(C.Structure):
@@ -28,12 +28,13 @@ class SaDesc(C.Structure):
                 ("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("out", vp), ("ldo", ci),
                 ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("cnt_ld", ci)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci)]
 
 
 class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float), ("W2s", vp), ("W3s", vp)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float), ("W2s", vp), ("W3s", vp),
+                ("w2_unscale", C.c_float), ("w3_unscale", C.c_float)]
 
 
 class SaModule(C.Structure):
@@ -41,7 +42,7 @@ class SaModule(C.Structure):
 
 
 class Dense(C.Structure):
-    _fields_ = [("W", vp), ("b", vp), ("post_scale", vp), ("post_shift", vp), ("O", ci), ("K", ci), ("ldw", ci), ("Ws", vp), ("ws_tile_rows", ci)]
+    _fields_ = [("W", vp), ("b", vp), ("post_scale", vp), ("post_shift", vp), ("O", ci), ("K", ci), ("ldw", ci), ("Ws", vp), ("ws_tile_rows", ci), ("w_unscale", C.c_float)]
 
 
 class Weights(C.Structure):

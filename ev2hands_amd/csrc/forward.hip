@@ -236,6 +236,7 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     d.precision = g_precision;
     d.Ws = (g_precision != EV2H_PREC_F32) ? w.Ws : nullptr;
     d.ws_tile_rows = w.ws_tile_rows;
+    d.w_unscale = w.w_unscale;
     return ev2h_gemm(&d, st);
 }
 
@@ -257,7 +258,7 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         d.W1x = br.W1x; d.W2 = br.W2; d.b2 = br.b2; d.W3 = br.W3; d.b3 = br.b3;
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
-        d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s;
+        d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
         static const bool no_skip = getenv("EV2H_SA_NO_SKIP") != nullptr;       // A/B switch: process padding strips too
         d.cnt = (cnt && !no_skip) ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
         char t[40];

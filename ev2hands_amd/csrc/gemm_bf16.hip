@@ -26,6 +26,7 @@ struct GemmBP {
     const float* post_scale; const float* post_shift;
     int taps; int Kc; int rows_per_seq;
     int rowmax_rows;
+    float w_unscale;        // power of two: the W planes are those of W / w_unscale, products are multiplied back (pack.py: plane_unscale)
     int tiles_n; int nblk;
     int debug;              // timing experiments only (EV2H_GEMM_DEBUG): bit0 skip W DMA after tile 0, bit1 skip X loads
 };
@@ -41,6 +42,7 @@ template <int NS>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
     using Cfg = GBCfg<NS>;
     constexpr int RS = Cfg::RS;
+    const float w_prescale = 1.f / p.w_unscale;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA0 = smem;
     char* sB0 = smem + Cfg::OPER;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
             const f32x4* g = reinterpret_cast<const f32x4*>(p.W + (long)(ok ? n : 0) * p.ldw + (ok ? k : 0));
             f32x4 v0 = g[0], v1 = g[1];
             if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
-            rb[0] = v0; rb[1] = v1;
+            rb[0] = v0 * w_prescale; rb[1] = v1 * w_prescale;       // exact (power of two)
         }
     };
     auto swrite_one = [&](char* dst, const f32x4 (&r)[2]) {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                float v = acc[i][r] + bj;
+                float v = acc[i][r] * p.w_unscale + bj;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.post_scale) v = __fmaf_rn(v, sj, tj);
                 if (row < p.M && okc) p.Y[(long)row * p.ldy + col] = v;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                float v = acc[i][r] + bj;
+                float v = acc[i][r] * p.w_unscale + bj;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.post_scale) v = __fmaf_rn(v, sj, tj);
                 if (row < p.M) mx = fmaxf(mx, v);
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] + bj[j];
+                    float v = acc[i][j][r] * p.w_unscale + bj[j];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
                     if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] + bj[j];
+                    float v = acc[i][j][r] * p.w_unscale + bj[j];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
                     if (row < p.M) mx[j] = fmaxf(mx[j], v);
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] + bj[j];
+                    float v = acc[i][j][r] * p.w_unscale + bj[j];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
                     if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] + bj[j];
+                    float v = acc[i][j][r] * p.w_unscale + bj[j];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
                     if (row < p.M) mx[j] = fmaxf(mx[j], v);
@@ -649,6 +651,7 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     p.bias = d->bias; p.bias_group_rows = d->bias_group_rows; p.ldbias = d->ldbias;
     p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
     p.rowmax_rows = d->rowmax_rows;
+    p.w_unscale = d->w_unscale > 0.f ? d->w_unscale : 1.f;
     static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
     p.debug = dbg;
     if (d->Ws && d->ws_tile_rows == 128) {   // 128-row plane images: three small workgroups per CU

@@ -30,6 +30,7 @@ struct SaBP {
     int B, Npts, S, K;
     int nblk;
     const int32_t* cnt; int cnt_ld;       // optional distinct-neighbour counts (ev2h_sa_desc.cnt)
+    float u2, u3;                         // power-of-two unscale factors of the W2s / W3s planes (ev2h_sa_desc.w2_unscale)
     int per_xcd;                          // resident variant: groups per XCD (multiple of 8); nblk is a multiple of 8
 };
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
         d[0] = w.x; d[4] = w.y; d[8] = w.z;
     }
-    for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i];
+    for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
 
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
     auto dma_tile = [&](const char* src, char* dst, int bytes) {
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 unsigned o[NS];
-                split_planes<NS>(relu_bits(h2[t][2 * k]), relu_bits(h2[t][2 * k + 1]), o);
+                split_planes<NS>(relu_bits(h2[t][2 * k] * p.u2), relu_bits(h2[t][2 * k + 1] * p.u2), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
     for (int u = 0; u < T3; ++u) {
         const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
-        if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v + p.b3[32 * u + l31], 0.f);
+        if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v * p.u3 + p.b3[32 * u + l31], 0.f);
     }
     if constexpr (!RES) break;
   }
@@ -408,6 +409,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.W1x = (const float4*)d->W1x; p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
     p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
+    p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);

@@ -96,20 +96,25 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     keep = None
     d.ws_tile_rows = w_tile_rows
     if w_image is not None:
-        d.Ws = w_image.data_ptr()
-    elif precision != "f32" and N >= 96 and presplit:
-        keep = make_w_image(W, precision, w_tile_rows)
+        keep, d.w_unscale = w_image
         d.Ws = keep.data_ptr()
+    elif precision != "f32" and N >= 96 and presplit:
+        keep, d.w_unscale = make_w_image(W, precision, w_tile_rows)
+        d.Ws = keep.data_ptr()
+    elif precision != "f32":
+        from .pack import NS_OF, plane_unscale
+        d.w_unscale = plane_unscale(W.detach().cpu().double().numpy(), NS_OF[precision])
     L = _lib.lib()
     _lib.check(L.ev2h_init(), "ev2h_init")
     _lib.check(L.ev2h_gemm(C.byref(d), _st()), "ev2h_gemm")
     return Y
 
 
-def make_w_image(W: torch.Tensor, precision: str, rows: int = 128) -> torch.Tensor:
+def make_w_image(W: torch.Tensor, precision: str, rows: int = 128):
     """bf16 plane images of a dense weight for the bf16 GEMM kernels (host-side packing, do it once per weight)."""
     from .pack import NS_OF, gemm_bf16_w_image
-    return torch.from_numpy(gemm_bf16_w_image(W.detach().cpu().double().numpy(), NS_OF[precision], rows)).to(W.device)
+    img, u = gemm_bf16_w_image(W.detach().cpu().double().numpy(), NS_OF[precision], rows)
+    return torch.from_numpy(img).to(W.device), u          # (device image, power-of-two unscale)
 
 
 def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None) -> torch.Tensor:
@@ -132,8 +137,8 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     keep = []
     if precision != "f32":
         from .pack import NS_OF, sa_bf16_images
-        i2, i3 = sa_bf16_images(W2[:C2].detach().cpu().double().numpy(), W3[:, :C2].detach().cpu().double().numpy(),
-                                NS_OF[precision])
+        i2, i3, d.w2_unscale, d.w3_unscale = sa_bf16_images(W2[:C2].detach().cpu().double().numpy(),
+                                                            W3[:, :C2].detach().cpu().double().numpy(), NS_OF[precision])
         keep = [torch.from_numpy(i2).to(P1.device), torch.from_numpy(i3).to(P1.device)]
         d.W2s, d.W3s = keep[0].data_ptr(), keep[1].data_ptr()
     _lib.check(_lib.lib().ev2h_sa_mlp_max(C.byref(d), _st()), "ev2h_sa_mlp_max")

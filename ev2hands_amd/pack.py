@@ -82,6 +82,20 @@ def split_bf16_planes(a: np.ndarray, ns: int):
     return planes
 
 
+def plane_unscale(W: np.ndarray, ns: int) -> float:
+    """Power of two u such that the planes are taken of W / u.  f16x2 only: fp16 has 5 exponent bits, so the low plane of a
+    weight below 2^-3 is subnormal and small-magnitude layers lose accuracy (measured 2.6e-4 at |W| ~ 1e-4).  Dividing by
+    u = 2^-k with max|W / u| in [2^13, 2^14) is exact and the kernels multiply the accumulated product by u (also exact)."""
+    if ns != 2:
+        return 1.0
+    m = float(np.abs(np.asarray(W, dtype=np.float64)).max()) if np.size(W) else 0.0
+    if m == 0.0 or not np.isfinite(m):
+        return 1.0
+    k = int(np.floor(np.log2(16384.0 / m)))
+    k = max(-24, min(k, 60))
+    return float(2.0 ** -k)
+
+
 def sa_bf16_geometry(C2: int):
     T2 = _up(C2, 32) // 32
     rem = C2 % 32
@@ -91,7 +105,11 @@ def sa_bf16_geometry(C2: int):
 
 def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     """Byte images of the LDS weight tiles of sa_mlp_max_bf16_kernel (see SaBCfg in csrc/sa_mlp_bf16.hip).
-    W2 [C2, C1], W3 [C3, C2] folded fp32 weights.  Returns (W2s, W3s) uint8 arrays."""
+    W2 [C2, C1], W3 [C3, C2] folded fp32 weights.  Returns (W2s, W3s, u2, u3): uint8 images of W2 / u2 and W3 / u3 and the
+    power-of-two factors (plane_unscale) the kernel multiplies back."""
+    u2, u3 = plane_unscale(W2, ns), plane_unscale(W3, ns)
+    W2 = np.asarray(W2, dtype=np.float64) / u2
+    W3 = np.asarray(W3, dtype=np.float64) / u3
     C2, C1 = W2.shape
     C3 = W3.shape[0]
     T2, C2P = sa_bf16_geometry(C2)
@@ -117,15 +135,18 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     for s_ in range(ns):
         blk = p3[s_].view(np.uint8).reshape(C3 // 32, 32, C2P * 2)
         img3[:, :, s_ * C2P * 2:(s_ + 1) * C2P * 2] = blk
-    return img2.reshape(-1), img3.reshape(-1)
+    return img2.reshape(-1), img3.reshape(-1), u2, u3
 
 
 GEMM_W_TILE_ROWS = 128     # rows per W image tile (128: occupancy kernel, 256: wide kernel)
 
 
-def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS) -> np.ndarray:
-    """bf16 plane images of a dense weight W [N, Ktot] for the bf16 GEMM kernels: for every `rows`-row N tile and
-    every 32-wide K tile one LDS tile image [rows][ns*64 + 16 bytes] (planes side by side, 16 B row pad)."""
+def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS):
+    """Plane images of a dense weight W [N, Ktot] for the 16-bit GEMM kernels: for every `rows`-row N tile and every 32-wide
+    K tile one LDS tile image [rows][ns*64 + 16 bytes] (planes side by side, 16 B row pad).  Returns (image, u): the planes
+    are those of W / u (plane_unscale)."""
+    u = plane_unscale(W, ns)
+    W = np.asarray(W, dtype=np.float64) / u
     N, K = W.shape
     tn, nk = _up(N, rows) // rows, _up(K, 32) // 32
     Wp = _pad(W, tn * rows, nk * 32)
@@ -135,7 +156,7 @@ def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS) -> n
     for s_ in range(ns):
         blk = planes[s_].reshape(tn, rows, nk, 32).transpose(0, 2, 1, 3)         # [tn, nk, rows, 32] uint16
         img[:, :, :, s_ * 64:(s_ + 1) * 64] = np.ascontiguousarray(blk).view(np.uint8).reshape(tn, nk, rows, 64)
-    return img.reshape(-1)
+    return img.reshape(-1), u
 
 
 class PackedWeights:
@@ -218,8 +239,11 @@ class PackedWeights:
         d.post_shift = self._dev(name + ".pt", post_shift) if post_shift is not None else None
         d.O, d.K, d.ldw = O, (ldw if K is None else K), ldw
         if self.ns and O >= 96:       # all but the tiny heads: pre-split W images, streamed by LDS-DMA
-            d.Ws = self._dev_bytes(name + ".Ws", gemm_bf16_w_image(_pad(W, O, ldw), self.ns))
+            img, d.w_unscale = gemm_bf16_w_image(_pad(W, O, ldw), self.ns)
+            d.Ws = self._dev_bytes(name + ".Ws", img)
             d.ws_tile_rows = GEMM_W_TILE_ROWS
+        else:
+            d.w_unscale = plane_unscale(W, self.ns)        # the kernel splits W / w_unscale on the fly
 
     def _group_all(self, arr, sd, prefix, nlayers):
         """sample_and_group_all concatenates [xyz(3), features(512)] (pointnet2_utils.py:155); our
@@ -254,7 +278,7 @@ class PackedWeights:
             br.b3 = self._dev(n + ".b3", bs[2])
             br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, K, float(r)
             if self.ns:
-                i2, i3 = sa_bf16_images(Ws[1], Ws[2], self.ns)
+                i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(Ws[1], Ws[2], self.ns)
                 br.W2s = self._dev_bytes(n + ".W2s", i2)
                 br.W3s = self._dev_bytes(n + ".W3s", i3)
         m.W1f = self._dev(prefix + ".W1f", np.concatenate(W1f, 0))

@@ -100,6 +100,9 @@ typedef struct ev2h_gemm_desc {
     const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in (ws_tile_rows)-row x 32-k LDS
                                     tiles (ev2hands_amd/pack.py: gemm_bf16_w_image); NULL = split W on the fly  */
     int ws_tile_rows;            /* 128 (three 4-wave workgroups per CU) or 256 (one 8-wave workgroup)           */
+    float w_unscale;             /* 16-bit precisions: W is used as W / w_unscale (Ws holds those planes) and the product is
+                                    multiplied by w_unscale before the bias; a power of two chosen by the host so that the
+                                    fp16 planes of small weights are not subnormal (pack.py: plane_unscale).  0 = 1.      */
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 
@@ -128,6 +131,7 @@ typedef struct ev2h_sa_desc {
     const void* W2s;             /* bf16 tile images of W2 / W3 for BF16 / BF16X3 (ev2hands_amd/pack.py), */
     const void* W3s;             /* NULL for F32                                                        */
     const int32_t* cnt;          /* optional: cnt[(b*S + s) * cnt_ld] = number of distinct neighbours of the group   */
+    float w2_unscale, w3_unscale;/* power-of-two factors the W2s / W3s planes were divided by (0 = 1), see ev2h_gemm_desc   */
     int cnt_ld;                  /* (ev2h_ball_query's count output); slots >= cnt repeat slot 0, so whole 32-slot
                                     strips of padding are skipped by the 16-bit kernels -- the max is unchanged.  NULL (or
                                     EV2H_PREC_F32) = process all K slots                                       */
@@ -195,7 +199,8 @@ typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;
     int C1, C2, C3, K;
     float radius;
-    const void* W2s; const void* W3s;   /* bf16 tile images (NULL unless precision != F32) */
+    const void* W2s; const void* W3s;   /* 16-bit tile images (NULL unless precision != F32) */
+    float w2_unscale, w3_unscale;       /* see ev2h_sa_desc */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
@@ -212,6 +217,7 @@ typedef struct ev2h_dense {       /* one folded Conv/Linear: W [O][ldw], b [O], 
     int O, K, ldw;
     const void* Ws;               /* bf16 plane images of W (NULL: split on the fly / F32)              */
     int ws_tile_rows;             /* rows per image tile: 128 or 256                                    */
+    float w_unscale;              /* see ev2h_gemm_desc                                                  */
 } ev2h_dense;
 
 typedef struct ev2h_weights {

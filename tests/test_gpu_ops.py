@@ -148,6 +148,52 @@ def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
     assert err < tol
 
 
+@pytest.mark.parametrize("wscale", [1e-2, 1e-4, 1e-6, 30.0])
+@pytest.mark.parametrize("N", [256, 22])
+def test_f16x2_weight_magnitude_does_not_matter(wscale, N):
+    """fp16 has 5 exponent bits: without the exact power-of-two pre-scaling of the weight planes (pack.py: plane_unscale) the low
+    plane of small weights is subnormal and the error reaches 2.6e-4 at |W| ~ 1e-4.  N = 22: the head layers, whose W is split
+    in the kernel (no plane image)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    M, K = 1024, 256
+    X = torch.from_numpy(synth.hash_normal("X", (M, K), 31)).float().cuda()
+    W = (torch.from_numpy(synth.hash_normal("W", (N, K), 32) / np.sqrt(K)).float() * wscale).cuda()
+    b = (torch.from_numpy(synth.hash_normal("b", (N,), 33)).float() * wscale).cuda()
+    ref = X.double() @ W.double().t() + b.double()
+    got = ops.dense(X, W, b, False, precision="f16x2")
+    assert rel(got, ref) < 4e-6
+
+
+@pytest.mark.parametrize("wscale", [1e-2, 1e-3])
+def test_sa_f16x2_small_weights(wscale):
+    """Small layer-2 / large layer-3 weights with activations kept O(1) .. O(1e3): the weight planes are pre-scaled exactly, so the
+    error stays at the 1e-6 level (activations themselves must stay within fp16's range)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    C1, C2, C3, K, B, Npts, S = 64, 96, 128, 128, 2, 512, 24
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, 77) * sc).float()
+    P1 = g("P1", (B, Npts, C1), 1.0 / wscale); xyz = cloud_xyz("U", B, Npts, 45); ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), 78)).int()
+    W1x = g("W1x", (C1, 3), 0.5 / wscale)
+    W2, b2 = g("W2", (C2, C1), C1 ** -0.5 * wscale), g("b2", (C2,), 0.1)                     # h2 stays O(1)
+    W3, b3 = g("W3", (C3, C2), C2 ** -0.5 * wscale), g("b3", (C3,), 0.1 * wscale)
+    bi = torch.arange(B).view(B, 1, 1)
+    rows = P1.double()[bi, gidx.long()]
+    dxyz = (xyz[bi, gidx.long()] - ctr.view(B, S, 1, 3)).double()
+    h1 = (rows + dxyz @ W1x.double().t()).clamp_min(0)
+    h2 = (h1 @ W2.double().t() + b2.double()).clamp_min(0)
+    ref = (h2 @ W3.double().t() + b3.double()).clamp_min(0).max(2)[0]
+    up = lambda x, m: (x + m - 1) // m * m
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = W1x
+    W2p = torch.zeros(up(C2, 32), C1); W2p[:C2] = W2
+    b2p = torch.zeros(up(C2, 32)); b2p[:C2] = b2
+    W3p = torch.zeros(C3, up(C2, 8)); W3p[:, :C2] = W3
+    got = ops.sa_mlp_max(P1.cuda(), ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2p.cuda(),
+                         b2p.cuda(), W3p.cuda(), b3.cuda(), C2, "f16x2")
+    assert rel(got, ref) < 8e-6
+
+
 SA_CASES = [(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128), (128, 128, 256, 64), (128, 196, 256, 128)]
 
 

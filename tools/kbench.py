@@ -45,7 +45,7 @@ def bench_sa(B=256, precision="f32"):
             import ctypes as C
             from ev2hands_amd import _lib
             from ev2hands_amd.pack import sa_bf16_images
-            i2, i3 = sa_bf16_images(W2[:C2].cpu().double().numpy(), W3[:, :C2].cpu().double().numpy(), _lib.PREC[precision])
+            i2, i3, u2, u3 = sa_bf16_images(W2[:C2].cpu().double().numpy(), W3[:, :C2].cpu().double().numpy(), _lib.PREC[precision])
             i2, i3 = torch.from_numpy(i2).cuda(), torch.from_numpy(i3).cuda()
             out = torch.empty(B, S, C3, device=d)
             dd = _lib.SaDesc()
@@ -53,6 +53,7 @@ def bench_sa(B=256, precision="f32"):
             dd.W1x, dd.b2, dd.b3, dd.W2s, dd.W3s = W1x.data_ptr(), b2.data_ptr(), b3.data_ptr(), i2.data_ptr(), i3.data_ptr()
             dd.out, dd.ldo = out.data_ptr(), C3
             dd.B, dd.Npts, dd.S, dd.K, dd.C1, dd.C2, dd.C3, dd.precision = B, Npts, S, K, C1, C2, C3, _lib.PREC[precision]
+            dd.w2_unscale, dd.w3_unscale = u2, u3
             L = _lib.lib()
             fn = lambda: _lib.check(L.ev2h_sa_mlp_max(C.byref(dd), _lib.stream_handle()), "sa")
         ms = timeit(fn)
