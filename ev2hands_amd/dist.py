@@ -36,11 +36,12 @@ def shard_fps_inits(inits, lo: int, hi: int):
 def pack_outputs(out: dict) -> torch.Tensor:
     """{'class_logits','left','right'} -> [B, 4N + 2*(22+2334+63)] float32 (one row per window)."""
     B = out["class_logits"].shape[0]
-    parts = [out["class_logits"].reshape(B, -1)]
+    logits = out["class_logits"]
+    parts = [logits.reshape(B, logits.shape[1] * logits.shape[2])]       # explicit widths: a shard may hold no window
     for side in ("left", "right"):
         d = out[side]
-        parts += [d["global_orient"], d["hand_pose"], d["betas"], d["transl"], d["vertices"].reshape(B, -1),
-                  d["j3d"].reshape(B, -1)]
+        parts += [d["global_orient"], d["hand_pose"], d["betas"], d["transl"], d["vertices"].reshape(B, synth.MANO_NV * 3),
+                  d["j3d"].reshape(B, 63)]
     return torch.cat(parts, 1).contiguous()
 
 
@@ -60,10 +61,31 @@ def unpack_outputs(buf: torch.Tensor, N: int, n_pose: int = synth.MANO_CMPS) -> 
     return out
 
 
-def all_gather_outputs(out: dict, N: int, group=None) -> dict:
-    """All ranks end up with the predictions of the whole global batch (equal shard sizes)."""
+def all_gather_outputs(out: dict, N: int, group=None, global_batch: int | None = None) -> dict:
+    """All ranks end up with the predictions of the whole global batch, in shard order.
+
+    `global_batch` = the batch that shard_range() split over the ranks.  Equal shards take ONE
+    all_gather_into_tensor; unequal shards (global_batch % world != 0) are padded to the largest shard for the
+    collective and trimmed afterwards.  Without `global_batch` the shard sizes are exchanged first (one small
+    collective) so that mismatched counts can never reach RCCL, where they hang instead of raising."""
     local = pack_outputs(out)
     world = dist.get_world_size(group)
-    full = torch.empty(world * local.shape[0], local.shape[1], device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(full, local, group=group)
-    return unpack_outputs(full, N)
+    rank = dist.get_rank(group)
+    if global_batch is None:
+        sizes_t = torch.zeros(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(sizes_t, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device), group=group)
+        sizes = [int(v) for v in sizes_t.tolist()]
+    else:
+        sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, world) for r in range(world))]
+    if sizes[rank] != local.shape[0]:
+        raise ValueError(f"rank {rank}: local batch {local.shape[0]} is not this rank's shard of {sizes} windows")
+    big = max(sizes)
+    if min(sizes) == big:
+        full = torch.empty(world * big, local.shape[1], device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(full, local, group=group)
+        return unpack_outputs(full, N)
+    padded = local if local.shape[0] == big else torch.cat([local, local.new_zeros(big - local.shape[0], local.shape[1])], 0)
+    full = torch.empty(world * big, local.shape[1], device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
+    rows = torch.cat([full[r * big:r * big + sizes[r]] for r in range(world)], 0)
+    return unpack_outputs(rows, N)

@@ -1,0 +1,49 @@
+"""bench.py's multi-rank plumbing on CPU: `python bench.py --gpus 2` invoked DIRECTLY (no torchrun) must start the two ranks
+itself, run the gloo all-gather and the max-over-ranks timing, and relay rank 0's single JSON line (--stub: fabricated
+predictions, no GPU).  Also: the same entry point under an external launcher environment, and the WORLD_SIZE mismatch error."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # the launcher path must not need a GPU
+    return env
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_direct_invocation_launches_its_own_ranks():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--batch", "3", "--points", "128"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["stub"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["world_size_seen"] == 2 and d["config"]["global_batch"] == 6
+    assert d["gathered_rows"] == 6 and d["gathered_rank_ids"] == [0, 1]       # both shards arrived through the all-gather
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["unit"] == "event-windows/s"
+    assert "roofline" not in d and "cpu_baseline" not in d                     # a stub line can never pass for a measurement
+
+
+def test_single_rank_stub_line_and_metric_string():
+    p = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "0", "--stub", "--batch", "2", "--points", "256"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 1 and d["metric"] == "event-windows/sec at B=2 N=256"
+    assert d["config"]["points"] == 256 and d["config"]["backend"] is None
+
+
+def test_world_size_mismatch_is_a_clear_error():
+    env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--stub"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)

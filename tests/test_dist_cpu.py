@@ -30,7 +30,7 @@ def _fake_outputs(lo, hi, N):
     return out
 
 
-def _worker(rank, world, port, gB, N, q):
+def _worker(rank, world, port, gB, N, q, pass_gb=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, gB, N, q):
     inits = synth.fps_inits(gB, N, 5)
     mine = evdist.shard_fps_inits(inits, lo, hi)
     assert all(m.shape[0] == hi - lo for m in mine) and torch.equal(mine[2], inits[2][lo:hi])
-    full = evdist.all_gather_outputs(_fake_outputs(lo, hi, N), N)
+    full = evdist.all_gather_outputs(_fake_outputs(lo, hi, N), N, global_batch=gB if pass_gb else None)
     want = _fake_outputs(0, gB, N)
     ok = torch.equal(full["class_logits"], want["class_logits"])
     for side in ("left", "right"):
@@ -48,12 +48,17 @@ def _worker(rank, world, port, gB, N, q):
     dist.destroy_process_group()
 
 
-def test_all_gather_of_sharded_predictions_world2():
-    world, gB, N = 2, 6, 64
+import pytest
+
+
+@pytest.mark.parametrize("gB,pass_gb", [(6, True), (7, True), (7, False), (1, True)])
+def test_all_gather_of_sharded_predictions_world2(gB, pass_gb):
+    """gB = 7 and 1: shards of unequal size (one rank may even own no window) are padded for the collective and trimmed."""
+    world, N = 2, 64
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, gB, N, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gB, N, q, pass_gb)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
