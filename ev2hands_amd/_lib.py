@@ -20,7 +20,9 @@ class GemmDesc(C.Structure):
                 ("M", ci), ("N", ci), ("K", ci),
                 ("bias", vp), ("bias_group_rows", ci), ("ldbias", ci), ("relu", ci),
                 ("post_scale", vp), ("post_shift", vp),
-                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci), ("w_unscale", C.c_float)]
+                ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci), ("w_unscale", C.c_float),
+                ("x_amax", vp), ("x_amax2", vp), ("x_group_rows", ci), ("y_amax", vp), ("y_group_rows", ci), ("y_scale", vp),
+                ("y_bound_w", C.c_float), ("y_bound_b", C.c_float)]
 
 
 class SaDesc(C.Structure):
@@ -28,17 +30,20 @@ class SaDesc(C.Structure):
                 ("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("out", vp), ("ldo", ci),
                 ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci),
+                ("p1_scale", vp), ("p1_amax", vp), ("w1x_norm", C.c_float), ("dmax", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
+                ("out_amax", vp)]
 
 
 class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
-                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_float), ("W2s", vp), ("W3s", vp),
-                ("w2_unscale", C.c_float), ("w3_unscale", C.c_float)]
+                ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_double), ("W2s", vp), ("W3s", vp),
+                ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("w1x_norm", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float)]
 
 
 class SaModule(C.Structure):
-    _fields_ = [("W1f", vp), ("b1", vp), ("kf", ci), ("npoint", ci), ("nbranch", ci), ("br", SaBranch * 3)]
+    _fields_ = [("W1f", vp), ("b1", vp), ("kf", ci), ("npoint", ci), ("nbranch", ci), ("br", SaBranch * 3),
+                ("w1f_unscale", C.c_float), ("w1f_norm", C.c_float), ("b1_max", C.c_float)]
 
 
 class Dense(C.Structure):
@@ -72,7 +77,7 @@ EXPORTS = [
     "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max",
-    "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano",
+    "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
     "ev2h_event_window_build", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions",
 ]
@@ -103,17 +108,18 @@ def lib() -> C.CDLL:
     L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
     L.ev2h_struct_sizes.restype = None
     L.ev2h_struct_sizes.argtypes = [C.c_size_t * 6]
-    L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+    L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
-    L.ev2h_ball_query.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_float), C.POINTER(ci), C.POINTER(vp), vp, vp]
-    L.ev2h_three_nn_interp.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp]
+    L.ev2h_ball_query.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(vp), vp, vp]
+    L.ev2h_three_nn_interp.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp, vp]
     L.ev2h_gemm.argtypes = [C.POINTER(GemmDesc), vp]
     L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, vp]
     L.ev2h_sa_mlp_max.argtypes = [C.POINTER(SaDesc), vp]
     L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
-    L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp, vp]
+    L.ev2h_mano_rotations.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp]
     L.ev2h_forward.argtypes = [C.POINTER(Weights), C.POINTER(ManoConsts), C.POINTER(ManoConsts), vp, ci, ci, ci, ci, vp,
                                C.POINTER(Outputs), vp, C.c_size_t, vp]
     L.ev2h_event_window_build.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp]
@@ -126,7 +132,7 @@ def lib() -> C.CDLL:
     mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs)]
     if list(sizes) != mine:
         raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
-    if L.ev2h_abi_version() != 2:      # 2: f16x2 precision, ev2h_sa_desc.cnt, ev2h_mesh_collisions
+    if L.ev2h_abi_version() != 3:      # 3: F16X2 range records (amax arguments, ev2h_gemm_desc / ev2h_sa_desc range fields)
         raise Ev2hError("ABI version mismatch")
     _lib = L
     return L

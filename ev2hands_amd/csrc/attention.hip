@@ -57,7 +57,8 @@ __global__ __launch_bounds__(1024) void attn_sim_kernel(const float4* __restrict
 // one wave per point: lanes hold 4 channels each of the 256-wide value row, both hands' sim in registers
 constexpr int CTX_PTS_PER_WAVE = 32;
 __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restrict__ sim, const float* __restrict__ value,
-                                                           int ldv, int N, size_t rows_total, float* __restrict__ hf8) {
+                                                           int ldv, int N, size_t rows_total, float* __restrict__ hf8,
+                                                           unsigned* __restrict__ amax, int amax_hand_stride) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 w[2][4];
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
         for (int c = 0; c < 4; ++c)
             w[h][c] = *reinterpret_cast<const float4*>(sim + (((size_t)b * 2 + h) * 4 + c) * ATT_D + lane * 4);
     const int n0 = (blockIdx.x * 4 + wave) * CTX_PTS_PER_WAVE;
+    unsigned am = 0u;
     for (int n = n0; n < n0 + CTX_PTS_PER_WAVE && n < N; ++n) {
         const size_t row = (size_t)b * N + n;
         const float4 v = *reinterpret_cast<const float4*>(value + row * ldv + lane * 4);
@@ -92,9 +94,17 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
         if ((lane & 7) == 0) {
             const int gsum = lane >> 3;
             hf8[((size_t)(gsum >> 2) * rows_total + row) * 8 + (gsum & 3)] = r;
+            am = max(am, __float_as_uint(r) & 0x7fffffffu);
         } else if ((lane & 7) == 4) {
             const int gsum = lane >> 3;
             hf8[((size_t)(gsum >> 2) * rows_total + row) * 8 + 4 + (gsum & 3)] = 0.f;
+        }
+    }
+    if (amax) {                          // range records of the two hands' context features (f16x2): lanes 0..31 hold hand 0
+        unsigned a0 = wave_max_u32_dpp(lane < 32 ? am : 0u), a1 = wave_max_u32_dpp(lane < 32 ? 0u : am);
+        if (lane == 0) {
+            if (a0) atomicMax(&amax[b], a0);
+            if (a1) atomicMax(&amax[amax_hand_stride + b], a1);
         }
     }
 }
@@ -110,11 +120,11 @@ extern "C" int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int 
     return EV2H_OK;
 }
 
-extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8,
-                                 ev2h_stream_t stream) {
+extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax,
+                                 int amax_hand_stride, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
     dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
-    attn_context_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8);
+    attn_context_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

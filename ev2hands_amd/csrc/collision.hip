@@ -167,12 +167,10 @@ extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_
     ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts};
     const size_t lds = (size_t)(3 * 2 * nv) * 4 + (size_t)(3 * 2 * nf) * 4 + (size_t)(6 * 2 * nf) * 4 + (size_t)(2 * nf + 1) * 4 +
                        COL_THREADS * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-        attr_set = true;
-    }
+                                           160 * 1024)););
     mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

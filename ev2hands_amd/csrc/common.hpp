@@ -33,6 +33,28 @@ void ev2h_set_error(const char* fmt, ...);
 
 #define EV2H_CHECK_LAUNCH() EV2H_CHECK_HIP(hipGetLastError())
 
+// Per-device, thread-safe one-time setup (kernel attributes such as the dynamic-LDS limit are per device, and a host may drive
+// several devices from several threads).  `slot` is a static PerDevice object at the call site; the setup itself is idempotent,
+// so two threads racing through it is harmless.
+#include <atomic>
+constexpr int EV2H_MAX_DEV = 16;
+struct PerDevice {
+    std::atomic<int> v[EV2H_MAX_DEV];
+    std::atomic<int>& cur() {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        return v[(dev >= 0 && dev < EV2H_MAX_DEV) ? dev : 0];
+    }
+};
+#define EV2H_ONCE_PER_DEVICE(slot, ...)                 \
+    do {                                                \
+        std::atomic<int>& f__ = (slot).cur();           \
+        if (!f__.load(std::memory_order_acquire)) {     \
+            __VA_ARGS__;                                \
+            f__.store(1, std::memory_order_release);    \
+        }                                               \
+    } while (0)
+
 // v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 (fmaf chain in k order).
 //   A: lane l holds A[i = l&31][k = l>>5];  B: lane l holds B[k = l>>5][j = l&31]
 //   D: lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]

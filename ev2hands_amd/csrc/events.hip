@@ -146,12 +146,10 @@ extern "C" int ev2h_event_window_build(const double* events, const int32_t* offs
                                        int32_t* uniq_count, float* uniq, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(events && offsets && uniq_count && uniq);
     EV2H_CHECK_ARG(B > 0 && width > 0 && height > 0 && width * height <= (1 << 17) && cap > 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(event_window_build_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, EVW_MAX_EVENTS * 4));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, EVW_MAX_EVENTS * 4)););
     event_window_build_kernel<<<B, EVW_THREADS, EVW_MAX_EVENTS * 4, (hipStream_t)stream>>>(events, offsets, width, height, cap, uniq_count, uniq);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

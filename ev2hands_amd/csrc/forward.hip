@@ -33,19 +33,13 @@ extern "C" void ev2h_struct_sizes(size_t out[6]) {
     out[5] = sizeof(ev2h_outputs);
 }
 
-extern "C" int ev2h_init(void) {
-    static bool done = false;
-    if (done) return EV2H_OK;
-    int rc = ev2h_gemm_init();
-    if (rc) return rc;
-    done = true;
-    return EV2H_OK;
-}
+extern "C" int ev2h_init(void) { return ev2h_gemm_init(); }     // per-device, thread-safe, idempotent (common.hpp: PerDevice)
 
 // ---------------------------------------------------------------------------------------- profiling hook
 // bench.py brackets ONE named launch site of ev2h_forward with caller-owned HIP events (recorded on the
 // forward's own stream), cycling through n event pairs so that K timed steps give K samples.
-static struct {
+// (per host thread: the thread that arms the hook is the one whose forwards are bracketed)
+static thread_local struct {
     char tag[32];
     hipEvent_t* start;
     hipEvent_t* stop;
@@ -81,21 +75,30 @@ static inline void prof_end(const char* tag, ev2h_stream_t st) {
 // MFMA-heavy kernels of the other and fill their tails: +1.5-2 % windows/s at B=256, outputs bit-identical
 // (tests/test_gpu_forward.py::test_two_stream_fork_is_bit_identical).  EV2H_TWO_STREAMS=0 keeps everything on the caller's
 // stream.  Kernels of the two hands then overlap in time, so bench.py brackets a launch site before the fork (sa2.1).
-static thread_local hipStream_t g_side = nullptr;
-static thread_local hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-static thread_local int g_side_state = 0;   // 0 = not tried, 1 = ready, -1 = disabled
+// One side stream (+ 4 events) per host thread AND per device: a second wrapper on another GPU in the same thread gets
+// its own stream on that device.
+struct SideCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
+};
+constexpr int EV2H_MAX_DEVICES = 16;
+static thread_local SideCtx g_side[EV2H_MAX_DEVICES];
 
-static bool side_ready() {
-    if (g_side_state == 0) {
+static SideCtx* side_ctx() {     // the current device's side stream, or nullptr (single-stream mode)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EV2H_MAX_DEVICES) return nullptr;
+    SideCtx& c = g_side[dev];
+    if (c.state == 0) {
         const char* e = getenv("EV2H_TWO_STREAMS");
-        g_side_state = -1;
-        if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) == hipSuccess) {
+        c.state = -1;
+        if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess) {
             bool ok = true;
-            for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) == hipSuccess;
-            if (ok) g_side_state = 1;
+            for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+            if (ok) c.state = 1;
         }
     }
-    return g_side_state == 1;
+    return c.state == 1 ? &c : nullptr;
 }
 
 // ---------------------------------------------------------------------------------------- small kernels
@@ -151,6 +154,19 @@ static const char* const kHandNames[2][10] = {
     {"P1mL", "fpsmL", "ctrmL", "gidxm0L", "gidxm1L", "cntmL", "m1bufL", "msa2hL", "m2L", "fc1L"},
     {"P1mR", "fpsmR", "ctrmR", "gidxm0R", "gidxm1R", "cntmR", "m1bufR", "msa2hR", "m2R", "fc1R"}};
 
+// F16X2 range records (ev2hands_hip.h "Range records"): one uint32 [B] array per tensor that a contraction reads
+enum RangeId {
+    R_FEAT, R_L1A, R_L1B, R_L2, R_SA3H1, R_SA3H2, R_L3, R_FP3H, R_FP3O, R_FP2H, R_L1NEW, R_FP1IN, R_FP1H1, R_FP1H2, R_L0, R_CLSH, R_Q1,
+    R_HF,            // two records: left, right
+    R_HF_R,
+    R_M1, R_M1_R, R_MSA2H, R_MSA2H_R, R_M2, R_M2_R, R_FC1, R_FC1_R,
+    R_P1A, R_P1B, R_P1M, R_P1M_R,
+    R_COUNT
+};
+static const char* const kRangeNames[R_COUNT] = {
+    "feat", "l1a", "l1b", "l2", "sa3h1", "sa3h2", "l3", "fp3h", "fp3o", "fp2h", "l1new", "fp1in", "fp1h1", "fp1h2", "l0", "clsh", "q1",
+    "hfL", "hfR", "m1L", "m1R", "msa2hL", "msa2hR", "m2L", "m2R", "fc1L", "fc1R", "p1a", "p1b", "p1mL", "p1mR"};
+
 static void build_layout(Layout& L, int B, int N) {
     const size_t R = (size_t)B * N;
     const size_t b = (size_t)B;
@@ -205,14 +221,26 @@ static void build_layout(Layout& L, int B, int N) {
         L.add(kHandNames[h][8], b * 512);
         L.add(kHandNames[h][9], b * 1024);
     }
+    L.add("ranges", (size_t)R_COUNT * b);       // F16X2 range records (uint32 [R_COUNT][B]) ...
+    L.add("p1scale", 4 * b);                    // ... and the storage scales of the four layer-1 tables (float [4][B])
     (void)hname;
 }
 
 struct Ws {
     char* base;
     Layout L;
+    int B = 0;
+    bool ranges_on = false;      // F16X2: range records are maintained and used
     float* f(const char* name) const { return reinterpret_cast<float*>(base + L.find(name)->off); }
     int32_t* i(const char* name) const { return reinterpret_cast<int32_t*>(base + L.find(name)->off); }
+    uint32_t* r(int id) const { return ranges_on ? reinterpret_cast<uint32_t*>(base + L.find("ranges")->off) + (size_t)id * B : nullptr; }
+    float* p1scale(int k) const { return ranges_on ? f("p1scale") + (size_t)k * B : nullptr; }
+};
+
+// range arguments of one dense layer: where X's record(s) live and where Y's goes
+struct Rng {
+    const uint32_t* xa = nullptr; const uint32_t* xa2 = nullptr; int xg = 0;
+    uint32_t* ya = nullptr; int yg = 0;
 };
 
 #define RUN(expr)                 \
@@ -223,10 +251,11 @@ struct Ws {
 
 static thread_local int g_precision = EV2H_PREC_F32;   // set by ev2h_forward for the helpers below (single in-flight forward per thread)
 
-static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st,
+static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st, const Rng& rg,
                  const float* group_bias = nullptr, int group_rows = 0, int ldbias = 0, int taps = 1, int rows_per_seq = 0,
                  int rowmax_rows = 0) {
     ev2h_gemm_desc d{};
+    d.x_amax = rg.xa; d.x_amax2 = rg.xa2; d.x_group_rows = rg.xg; d.y_amax = rg.ya; d.y_group_rows = rg.yg;
     d.X = X; d.ldx = ldx; d.W = w.W; d.ldw = w.ldw; d.Y = Y; d.ldy = ldy;
     d.M = M; d.N = w.O; d.K = w.K;
     d.bias = group_bias ? group_bias : w.b;
@@ -240,15 +269,28 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     return ev2h_gemm(&d, st);
 }
 
-// one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius
+// one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius.
+// Range records (F16X2): feat_amax / feat_amax2 = records of the table's input rows, p1_amax / p1_scale = record and storage scale
+// of the table, out_amax = record of the module's output.
 static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
-                     int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st) {
+                     int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st,
+                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax) {
     int c1sum = 0;
-    for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
+    float extra = 0.f;                   // max over the branches of |W1x|_1 * radius: what layer 1 adds to a table entry
+    for (int i = 0; i < m.nbranch; ++i) {
+        c1sum += m.br[i].C1;
+        extra = fmaxf(extra, m.br[i].w1x_norm * (float)m.br[i].radius * 1.0000002f);
+    }
     ev2h_gemm_desc g{};
     g.X = feat; g.ldx = ldf; g.W = m.W1f; g.ldw = m.kf; g.Y = P1; g.ldy = c1sum;
     g.M = B * Npts; g.N = c1sum; g.K = m.kf; g.bias = m.b1; g.taps = 1;
     g.precision = precision;
+    g.w_unscale = m.w1f_unscale;
+    if (feat_amax) {
+        g.x_amax = feat_amax; g.x_group_rows = Npts;
+        g.y_amax = p1_amax; g.y_group_rows = Npts;
+        g.y_scale = p1_scale; g.y_bound_w = m.w1f_norm; g.y_bound_b = m.b1_max + extra;
+    }
     RUN(ev2h_gemm(&g, st));
     int coff1 = 0, coff3 = 0;
     for (int i = 0; i < m.nbranch; ++i) {
@@ -259,6 +301,10 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
+        if (feat_amax) {
+            d.p1_scale = p1_scale; d.p1_amax = p1_amax; d.out_amax = out_amax;
+            d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
+        }
         static const bool no_skip = getenv("EV2H_SA_NO_SKIP") != nullptr;       // A/B switch: process padding strips too
         d.cnt = (cnt && !no_skip) ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
         char t[40];
@@ -285,35 +331,41 @@ extern "C" const void* ev2h_workspace_buffer(void* workspace, int B, int N, cons
     if (!workspace || !name || B <= 0 || N <= 0) return nullptr;
     Layout L;
     build_layout(L, B, N);
+    if (!strncmp(name, "rng.", 4)) {                  // one F16X2 range record: "rng.<tensor>" -> uint32 [B]
+        for (int i = 0; i < R_COUNT; ++i)
+            if (!strcmp(name + 4, kRangeNames[i])) {
+                if (count) *count = (size_t)B;
+                return static_cast<char*>(workspace) + L.find("ranges")->off + (size_t)i * B * 4;
+            }
+        return nullptr;
+    }
     const Buf* b = L.find(name);
     if (!b) return nullptr;
     if (count) *count = b->count;
     return static_cast<char*>(workspace) + b->off;
 }
 
-extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
-                            float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
-                            void* workspace, size_t workspace_bytes, ev2h_stream_t st) {
-    EV2H_CHECK_ARG(w && mano_left && mano_right && xyz_cm && fps_init && out && workspace);
-    EV2H_CHECK_ARG(B > 0 && N >= 128 && N <= 8192 && (C == 4 || C == 5));
-    EV2H_CHECK_ARG(out->class_logits && out->params[0] && out->params[1] && out->vertices[0] && out->vertices[1] &&
-                   out->joints[0] && out->joints[1]);
-    EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
-    EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
-    RUN(ev2h_init());
-    g_precision = w->precision;
-    Ws ws;
-    ws.base = static_cast<char*>(workspace);
-    build_layout(ws.L, B, N);
-    if (workspace_bytes < ws.L.total) {
-        ev2h_set_error("ev2h_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.L.total);
-        return EV2H_ERR_WORKSPACE;
-    }
+static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* mano, float* xyz_cm, int B, int C, int N, int mhlnes,
+                        const int64_t* fps_init, const ev2h_outputs* out, const Ws& ws, ev2h_stream_t st, SideCtx* side, bool* forked) {
     const int R = B * N;
-    const ev2h_mano_consts* mano[2] = {mano_left, mano_right};
+    const int prec = w->precision;
+    const Rng none{};
+    auto rg = [&](int xid, int xg, int yid = -1, int yg = 0, int xid2 = -1) {
+        Rng r{};
+        if (ws.ranges_on) {
+            r.xa = ws.r(xid); r.xg = xg;
+            if (xid2 >= 0) r.xa2 = ws.r(xid2);
+            if (yid >= 0) { r.ya = ws.r(yid); r.yg = yg; }
+        }
+        return r;
+    };
+    if (ws.ranges_on) {
+        const Buf* rb = ws.L.find("ranges");
+        EV2H_CHECK_HIP(hipMemsetAsync(ws.base + rb->off, 0, rb->count * 4, (hipStream_t)st));
+    }
 
     // ---- input layout + all three samplings of the raw cloud (enc.sa1, left.sa1, right.sa1)
-    RUN(ev2h_prep_points(xyz_cm, B, C, N, mhlnes, ws.f("pts4"), ws.f("feat8"), st));
+    RUN(ev2h_prep_points(xyz_cm, B, C, N, mhlnes, ws.f("pts4"), ws.f("feat8"), ws.r(R_FEAT), st));
     {
         const int S[3] = {512, 128, 128};
         const int64_t* init[3] = {fps_init, fps_init + 2 * (size_t)B, fps_init + 3 * (size_t)B};
@@ -322,97 +374,138 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
     }
     // fork 1: both hands' ball queries only need the raw cloud and their centroids
-    const bool fork = side_ready();
-    ev2h_stream_t sd = fork ? (ev2h_stream_t)g_side : st;
+    const bool fork = side != nullptr;
+    ev2h_stream_t sd = fork ? (ev2h_stream_t)side->stream : st;
     if (fork) {
-        EV2H_CHECK_HIP(hipEventRecord(g_ev[0], (hipStream_t)st));
-        EV2H_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev[0], 0));
+        EV2H_CHECK_HIP(hipEventRecord(side->ev[0], (hipStream_t)st));
+        EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[0], 0));
+        *forked = true;
     }
     for (int h = 0; h < 2; ++h) {
         const ev2h_sa_module& m = w->mano_sa1[h];
         const char* const* nm = kHandNames[h];
-        float rad[2]; int ns[2];
+        double rad[2]; int ns[2];
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
         for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f(nm[2]), B, N, 128, 2, rad, ns, gi, ws.i(nm[5]), sd));
     }
-    if (fork) EV2H_CHECK_HIP(hipEventRecord(g_ev[1], g_side));
+    if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[1], side->stream));
     // ---- enc.sa1 (TEHNet.py:179)
     {
         const ev2h_sa_module& m = w->sa1;
-        float rad[3]; int ns[3];
+        double rad[3]; int ns[3];
         int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
-        RUN(sa_module(w->precision, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st));
+        RUN(sa_module(prec, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st,
+                      ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A)));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
     {
         const ev2h_sa_module& m = w->sa2;
         RUN(ev2h_fps(ws.f("ctr1"), B, 512, 128, fps_init + (size_t)B, ws.i("fps2"), ws.f("ctr2"), st));
-        float rad[2]; int ns[2];
+        double rad[2]; int ns[2];
         int32_t* gi[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
         for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi, ws.i("cnt2"), st));
-        RUN(sa_module(w->precision, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st));
+        RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
+                      ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2)));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
                                                                                    ws.f("l2buf"), 520, 512);
         EV2H_CHECK_LAUNCH();
     }
     // ---- enc.sa3 group-all (TEHNet.py:181): 515 -> 256 -> 512 -> 1024, max over the 128 points
-    RUN(dense(w->sa3[0], ws.f("l2buf"), 520, B * 128, ws.f("sa3h1"), 256, 1, st));
-    RUN(dense(w->sa3[1], ws.f("sa3h1"), 256, B * 128, ws.f("sa3h2"), 512, 1, st));
-    RUN(dense(w->sa3[2], ws.f("sa3h2"), 512, B * 128, ws.f("l3"), 1024, 1, st, nullptr, 0, 0, 1, 0, 128));
+    // (the xyz columns of l2buf are input coordinates: the input's record R_FEAT bounds them)
+    RUN(dense(w->sa3[0], ws.f("l2buf"), 520, B * 128, ws.f("sa3h1"), 256, 1, st, rg(R_L2, 128, R_SA3H1, 128, R_FEAT)));
+    RUN(dense(w->sa3[1], ws.f("sa3h1"), 256, B * 128, ws.f("sa3h2"), 512, 1, st, rg(R_SA3H1, 128, R_SA3H2, 128)));
+    RUN(dense(w->sa3[2], ws.f("sa3h2"), 512, B * 128, ws.f("l3"), 1024, 1, st, rg(R_SA3H2, 128, R_L3, 1), nullptr, 0, 0, 1, 0, 128));
     // ---- fp3 (TEHNet.py:184): the single l3 point is broadcast, so its 1024 inputs collapse to a per-window bias
-    RUN(dense(w->fp3_bcast, ws.f("l3"), 1024, B, ws.f("fp3bias"), 256, 0, st));
-    RUN(dense(w->fp3_skip, ws.f("l2buf"), 520, B * 128, ws.f("fp3h"), 256, 1, st, ws.f("fp3bias"), 128, 256));
-    RUN(dense(w->fp3_1, ws.f("fp3h"), 256, B * 128, ws.f("fp3o"), 256, 1, st));
+    RUN(dense(w->fp3_bcast, ws.f("l3"), 1024, B, ws.f("fp3bias"), 256, 0, st, rg(R_L3, 1)));
+    RUN(dense(w->fp3_skip, ws.f("l2buf"), 520, B * 128, ws.f("fp3h"), 256, 1, st, rg(R_L2, 128, R_FP3H, 128, R_FEAT), ws.f("fp3bias"), 128, 256));
+    RUN(dense(w->fp3_1, ws.f("fp3h"), 256, B * 128, ws.f("fp3o"), 256, 1, st, rg(R_FP3H, 128, R_FP3O, 128)));
     // ---- fp2 (TEHNet.py:185): 3-NN 128 -> 512, concat [skip 320 | interpolated 256]
     RUN(ev2h_three_nn_interp(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, ws.f("fp3o"), 256, 256, ws.f("l1cat") + 320, 576,
-                             ws.i("nn2_idx"), ws.f("nn2_w"), st));
-    RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st));
-    RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st));
+                             ws.i("nn2_idx"), ws.f("nn2_w"), ws.r(R_L1B), st));
+    RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st, rg(R_L1A, 512, R_FP2H, 512, R_L1B)));
+    RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st, rg(R_FP2H, 512, R_L1NEW, 512)));
     // ---- fp1 (TEHNet.py:186): 3-NN 512 -> N, no skip
     RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
-                             ws.i("nn1_idx"), ws.f("nn1_w"), st));
-    RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st));
-    RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st));
-    RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st));
+                             ws.i("nn1_idx"), ws.f("nn1_w"), ws.r(R_FP1IN), st));
+    RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));
+    RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st, rg(R_FP1H1, N, R_FP1H2, N)));
+    RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st, rg(R_FP1H2, N, R_L0, N)));
     // ---- classifier (TEHNet.py:188)
-    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, st));
-    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, st));
+    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, st, rg(R_L0, N, R_CLSH, N)));
+    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, st, rg(R_CLSH, N)));
     RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, st));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
-    RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, nullptr, 0, 0, 3, N));
+    RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N, R_Q1, N), nullptr, 0, 0, 3, N));
     for (int h = 0; h < 2; ++h)
-        RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, nullptr, 0, 0, 3, N));
+        RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
     // ---- attention (TEHNet.py:13-27)
     RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
-    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), st));
+    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
     if (fork) {
-        EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, g_ev[1], 0));       // ball queries done
-        EV2H_CHECK_HIP(hipEventRecord(g_ev[2], (hipStream_t)st));              // attention output (hf8) ready
-        EV2H_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev[2], 0));
+        EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[1], 0));       // ball queries done
+        EV2H_CHECK_HIP(hipEventRecord(side->ev[2], (hipStream_t)st));              // attention output (hf8) ready
+        EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[2], 0));
     }
     for (int h = 0; h < 2; ++h) {
         const ev2h_sa_module& m = w->mano_sa1[h];
         const char* const* nm = kHandNames[h];
         ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
-        RUN(sa_module(w->precision, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh));
+        RUN(sa_module(prec, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh,
+                      ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h)));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)sh>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
                                                                                    ws.f(nm[6]), 520, 512);
         EV2H_CHECK_LAUNCH();
-        RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh));
-        RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, nullptr, 0, 0, 1, 0, 128));
-        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh));
-        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh));
-        RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
+        RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh, rg(R_M1 + h, 128, R_MSA2H + h, 128, R_FEAT)));
+        RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, rg(R_MSA2H + h, 128, R_M2 + h, 1), nullptr, 0, 0, 1, 0, 128));
+        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh, rg(R_M2 + h, 1, R_FC1 + h, 1)));
+        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh, rg(R_FC1 + h, 1)));
+        if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
     }
-    if (fork) {                                                                // join
-        EV2H_CHECK_HIP(hipEventRecord(g_ev[3], g_side));
-        EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, g_ev[3], 0));
-    }
+    (void)none;
     return EV2H_OK;
+}
+
+extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
+                            float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
+                            void* workspace, size_t workspace_bytes, ev2h_stream_t st) {
+    EV2H_CHECK_ARG(w && xyz_cm && fps_init && out && workspace);
+    EV2H_CHECK_ARG(B > 0 && N >= 128 && N <= 8192 && (C == 4 || C == 5));
+    EV2H_CHECK_ARG(out->class_logits && out->params[0] && out->params[1]);
+    // a NULL hand model skips that hand's MANO layer (the caller applies its own to params[h], TEHNet.py:103)
+    EV2H_CHECK_ARG(!mano_left || (out->vertices[0] && out->joints[0]));
+    EV2H_CHECK_ARG(!mano_right || (out->vertices[1] && out->joints[1]));
+    EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
+    EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
+    RUN(ev2h_init());
+    g_precision = w->precision;
+    Ws ws;
+    ws.base = static_cast<char*>(workspace);
+    ws.B = B;
+    ws.ranges_on = (w->precision == EV2H_PREC_F16X2);
+    build_layout(ws.L, B, N);
+    if (workspace_bytes < ws.L.total) {
+        ev2h_set_error("ev2h_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.L.total);
+        return EV2H_ERR_WORKSPACE;
+    }
+    const ev2h_mano_consts* mano[2] = {mano_left, mano_right};
+    SideCtx* side = side_ctx();
+    bool forked = false;
+    const int rc = forward_body(w, mano, xyz_cm, B, C, N, mhlnes, fps_init, out, ws, st, side, &forked);
+    if (forked) {
+        // join -- also on an error after the fork, so that the side stream is never left dangling (a stream capture of the
+        // caller's stream would otherwise be invalidated by the un-joined fork)
+        const hipError_t e1 = hipEventRecord(side->ev[3], side->stream);
+        const hipError_t e2 = hipStreamWaitEvent((hipStream_t)st, side->ev[3], 0);
+        if (rc == EV2H_OK && (e1 != hipSuccess || e2 != hipSuccess)) {
+            ev2h_set_error("ev2h_forward: joining the side stream failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            return EV2H_ERR_HIP;
+        }
+    }
+    return rc;
 }

@@ -190,9 +190,11 @@ __global__ __launch_bounds__(256) void transpose_logits_kernel(const float4* __r
 
 }  // namespace
 
-int ev2h_gemm_init() {
-    EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+int ev2h_gemm_init() {       // per device (ev2h_init)
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES)););
     return EV2H_OK;
 }
 

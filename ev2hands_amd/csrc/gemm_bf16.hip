@@ -27,6 +27,11 @@ struct GemmBP {
     int taps; int Kc; int rows_per_seq;
     int rowmax_rows;
     float w_unscale;        // power of two: the W planes are those of W / w_unscale, products are multiplied back (pack.py: plane_unscale)
+    // f16x2 activation range (planes.hpp header; all optional, ignored by the other modes)
+    const unsigned* x_amax; const unsigned* x_amax2; int x_group_rows;   // max|X| per group of x_group_rows rows (max of the two sources)
+    unsigned* y_amax; int y_group_rows;                                   // out: atomicMax of |Y| per group of output rows
+    float* y_scale; float y_bound_w, y_bound_b;                           // out: Y is stored times the power of two that keeps
+                                                                          // (y_bound_w * max|X| + y_bound_b) * s below 2^15
     int tiles_n; int nblk;
     int debug;              // timing experiments only (EV2H_GEMM_DEBUG): bit0 skip W DMA after tile 0, bit1 skip X loads
 };
@@ -37,6 +42,133 @@ struct GBCfg {
     static constexpr int OPER = GB_BM * RS;                 // one operand tile
     static constexpr int LDS_BYTES = 4 * OPER;              // 2 buffers x (A, B)
 };
+
+
+// power-of-two scale of X row m (f16x2 with a range record, 1 otherwise)
+template <int NS>
+__device__ __forceinline__ float x_row_scale(const GemmBP& p, long m) {
+    if constexpr (NS != 2) return 1.f;
+    if (!p.x_amax) return 1.f;
+    const long mm = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
+    const long g = mm / p.x_group_rows;
+    unsigned a = p.x_amax[g];
+    if (p.x_amax2) a = max(a, p.x_amax2[g]);
+    return f16x2_scale(a);
+}
+template <int NS>
+__device__ __forceinline__ void scale_rows(f32x4& v, float s) {
+    if constexpr (NS == 2) v *= s;       // exact (power of two); the products are multiplied back in the epilogue
+}
+
+// Epilogue shared by the three kernels.  acc[i][j][r] = output (row m0 + row0 + 32 i + mfma_row(r, half), column col0 + 32 j + l31):
+//   v = acc * (w_unscale / x_scale(row)) + bias;  ReLU;  post affine;  [* y_scale];  store, or max over the tile's 128 rows;
+//   optional atomicMax of |v| into the output's range record.
+template <int NS, int NI, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI][NJ], int m0, int row0, int col0, int wm, int wcol, int tile_cols,
+                                              float* red, int tid) {
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const float* bias = p.bias;
+    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
+    float bj[NJ], sj[NJ], tj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = col0 + j * 32 + l31;
+        const bool okc = col < p.N;
+        bj[j] = (bias && okc) ? bias[col] : 0.f;
+        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
+        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
+    }
+    // x scale (and the table storage scale y_scale): one per tile when the tile lies inside one group, else one per row
+    const bool xs_on = (NS == 2) && p.x_amax != nullptr;
+    const bool ys_on = (NS == 2) && p.y_scale != nullptr;
+    const bool xs_uniform = !xs_on || (p.x_group_rows % GB_BM) == 0;
+    auto y_store_scale = [&](long row) {          // power of two that keeps y_bound_w * max|X_g| + y_bound_b below 2^15
+        const long rr = row < p.M ? row : p.M - 1;
+        const long g = rr / p.x_group_rows;
+        unsigned a = p.x_amax[g];
+        if (p.x_amax2) a = max(a, p.x_amax2[g]);
+        return f16x2_scale(__float_as_uint(__fmaf_rn(p.y_bound_w, __uint_as_float(a), p.y_bound_b)));
+    };
+    float cx_u = p.w_unscale;
+    float sy_u = 1.f;
+    if (xs_on && xs_uniform) cx_u = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
+    if (ys_on && xs_uniform) sy_u = y_store_scale(m0);
+    unsigned am = 0u;
+    const bool track = (NS == 2) && p.y_amax != nullptr;
+    const bool y_uniform = (p.y_group_rows % GB_BM) == 0;
+    if (p.rowmax_rows == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + row0 + i * 32 + mfma_row(r, half);
+                const float cx = xs_uniform ? cx_u : p.w_unscale * pow2_inverse(x_row_scale<NS>(p, row));
+                const float sy = (xs_uniform || !ys_on) ? sy_u : y_store_scale(row);
+                if (ys_on && row < p.M && (row % p.y_group_rows) == 0 && col0 + l31 == 0) p.y_scale[row / p.y_group_rows] = sy;
+                unsigned amr = 0u;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int col = col0 + j * 32 + l31;
+                    float v = acc[i][j][r] * cx + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if constexpr (NS == 2) v *= sy;
+                    if (row < p.M && col < p.N) {
+                        p.Y[(long)row * p.ldy + col] = v;
+                        amr = max(amr, abs_bits(v));
+                    }
+                }
+                if (track) {
+                    if (y_uniform) am = max(am, amr);
+                    else {               // groups that straddle tiles, or one row per group: reduce over the 32 columns of the half-wave
+#pragma unroll
+                        for (int o = 16; o >= 1; o >>= 1) amr = max(amr, (unsigned)__shfl_xor((int)amr, o, 64));
+                        if (l31 == 0 && row < p.M && amr) atomicMax(&p.y_amax[row / p.y_group_rows], amr);
+                    }
+                }
+            }
+        if (track && y_uniform) {
+            am = wave_max_u32_dpp(am);
+            if (lane == 0 && am) atomicMax(&p.y_amax[m0 / p.y_group_rows], am);
+        }
+    } else {
+        // group-all max over the tile's 128 rows (rowmax_rows == 128: one window per tile; x scale tile-uniform)
+        __syncthreads();                 // operand tiles are dead
+        float mx[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mx[j] = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + row0 + i * 32 + mfma_row(r, half);
+                    float v = acc[i][j][r] * cx_u + bj[j];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                    if (row < p.M) mx[j] = fmaxf(mx[j], v);
+                }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
+            if (half == 0) red[wm * tile_cols + wcol + j * 32 + l31] = mx[j];
+        }
+        __syncthreads();
+        if (tid < tile_cols) {
+            const int c = col0 - wcol + tid;
+            float v = fmaxf(red[tid], red[tile_cols + tid]);
+            if (c < p.N) {
+                p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = v;
+                am = abs_bits(v);
+            }
+        }
+        if (track && tid < tile_cols) {
+            am = wave_max_u32_dpp(am);
+            if (lane == 0 && am) atomicMax(&p.y_amax[(m0 / p.rowmax_rows) / p.y_group_rows], am);
+        }
+    }
+}
 
 template <int NS>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
@@ -59,6 +191,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
     // loader: thread -> (row = tid / 4, 8 consecutive k = (tid % 4) * 8) of the A tile and of the B tile
     const int lrow = tid >> 2, lseg = tid & 3;
     f32x4 ra[2], rb[2];
+    const float xs = x_row_scale<NS>(p, m0 + lrow);
 
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 8;
@@ -78,6 +211,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
             const f32x4* g = reinterpret_cast<const f32x4*>(p.X + mm * p.ldx + kk);
             f32x4 v0 = g[0], v1 = g[1];
             if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            scale_rows<NS>(v0, xs); scale_rows<NS>(v1, xs);
             ra[0] = v0; ra[1] = v1;
         }
         {
@@ -102,11 +236,11 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
         }
     };
 
-    f32x16 acc[2];
+    f32x16 acc[2][1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
     const int nk = (p.K + GB_BK - 1) / GB_BK;
     gload(0);
@@ -130,8 +264,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
             }
 #pragma unroll
             for (int q = 0; q < Planes<NS>::NPROD; ++q) {
-                acc[0] = mfma_planes<NS>(a0[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[0]);
-                acc[1] = mfma_planes<NS>(a1[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[1]);
+                acc[0][0] = mfma_planes<NS>(a0[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[0][0]);
+                acc[1][0] = mfma_planes<NS>(a1[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[1][0]);
             }
         }
         if (kt + 1 < nk) {
@@ -140,57 +274,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
         }
         __syncthreads();
     }
-
-    // ------------------------------------------------------------------ epilogue (fp32)
-    const float* bias = p.bias;
-    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
-    const int col = n0 + wn * 32 + l31;
-    const bool okc = col < p.N;
-    const float bj = (bias && okc) ? bias[col] : 0.f;
-    const float sj = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
-    const float tj = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
-    if (p.rowmax_rows == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                float v = acc[i][r] * p.w_unscale + bj;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.post_scale) v = __fmaf_rn(v, sj, tj);
-                if (row < p.M && okc) p.Y[(long)row * p.ldy + col] = v;
-            }
-    } else {
-        float* red = reinterpret_cast<float*>(smem);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                float v = acc[i][r] * p.w_unscale + bj;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (p.post_scale) v = __fmaf_rn(v, sj, tj);
-                if (row < p.M) mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (half == 0) red[wm * GB_BN + wn * 32 + l31] = mx;
-        __syncthreads();
-        if (tid < GB_BN) {
-            const int c = n0 + tid;
-            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GB_BN + tid]);
-        }
-    }
+    gemm_epilogue<NS, 2, 1>(p, acc, m0, wm * 64, n0 + wn * 32, wm, wn * 32, GB_BN, reinterpret_cast<float*>(smem), tid);
 }
 
 template <int NS>
 int launch_gb(const GemmBP& p, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GBCfg<NS>::LDS_BYTES));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GBCfg<NS>::LDS_BYTES)););
     gemm_nt_bf16_kernel<NS><<<p.nblk, GB_THREADS, GBCfg<NS>::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
@@ -231,6 +323,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
     const int nk = (p.K + GB_BK - 1) / GB_BK;
     f32x4 ra[2];             // X rows of the next K tile, in flight while the current tile is multiplied
     bool oka = true;         // zero fill is applied when the tile is written to LDS, not on the load
+    const float xs = x_row_scale<NS>(p, m0 + lrow);
 
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 8;
@@ -255,6 +348,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
     auto swrite = [&](char* dst) {
         f32x4 r[2] = {ra[0], ra[1]};
         if (!oka) { r[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[1] = r[0]; }
+        scale_rows<NS>(r[0], xs); scale_rows<NS>(r[1], xs);
         unsigned q[4][NS];
         split_planes<NS>(r[0][0], r[0][1], q[0]);
         split_planes<NS>(r[0][2], r[0][3], q[1]);
@@ -325,69 +419,15 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         __builtin_amdgcn_s_barrier();
     }
 
-    const float* bias = p.bias;
-    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
-    float bj[2], sj[2], tj[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        const bool okc = col < p.N;
-        bj[j] = (bias && okc) ? bias[col] : 0.f;
-        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
-        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
-    }
-    if (p.rowmax_rows == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] * p.w_unscale + bj[j];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
-                    if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
-                }
-            }
-    } else {
-        float* red = reinterpret_cast<float*>(smem);
-        float mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] * p.w_unscale + bj[j];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
-                    if (row < p.M) mx[j] = fmaxf(mx[j], v);
-                }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
-        if (half == 0) {
-            red[wm * GW_BN + wn * 64 + l31] = mx[0];
-            red[wm * GW_BN + wn * 64 + 32 + l31] = mx[1];
-        }
-        __syncthreads();
-        if (tid < GW_BN) {
-            const int c = n0 + tid;
-            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GW_BN + tid]);
-        }
-    }
+    gemm_epilogue<NS, 2, 2>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GW_BN, reinterpret_cast<float*>(smem), tid);
 }
 
 template <int NS>
 int launch_gw(const GemmBP& p, const char* Ws, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_wide_kernel<NS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GWCfg<NS>::LDS_BYTES));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GWCfg<NS>::LDS_BYTES)););
     gemm_nt_bf16_wide_kernel<NS><<<p.nblk, GB_THREADS, GWCfg<NS>::LDS_BYTES, st>>>(p, Ws);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
@@ -430,12 +470,20 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
     const int lrow = tid >> 1, lseg = tid & 1;            // loader: row, 16-wide k half
     const int nk = (p.K + GB_BK - 1) / GB_BK;
     f32x4 ra[4], rh[4];
-    bool oka = true, okh = true;
+    bool oka = true, okh = true, fulla = true;      // fulla: all 16 floats of the segment lie inside the row (k + 16 <= K)
+    const float xs = x_row_scale<NS>(p, m0 + lrow);
+    // halo rows (TAP3, threads 0..3): rows m0 - 1 and m0 + 128 lie in the tile's window whenever they are used
+    const float xsh = TAP3 ? x_row_scale<NS>(p, (tid >> 1) ? (long)m0 + GB_BM : (long)m0 - 1) : 1.f;
 
-    auto load16 = [&](const float* g, f32x4 (&r)[4]) {
+    // 16 consecutive floats of one X row.  K is a multiple of 8, not of 16: when only the first 8 lie inside the row (`full`
+    // false) the second half is read from the first half's address -- never past the row -- and zeroed when the tile is
+    // written (swrite_row): the floats behind a row's end belong to the NEXT row, and although their weights are zero a
+    // neighbour window's value times this window's power-of-two scale can overflow fp16 (inf * 0 = NaN).
+    auto load16 = [&](const float* g, bool full, f32x4 (&r)[4]) {
+        const float* g2 = full ? g + 8 : g;
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
-                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(g) : "memory");
+                     "global_load_dwordx4 %2, %5, off\n\tglobal_load_dwordx4 %3, %5, off offset:16"
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(g), "v"(g2) : "memory");
     };
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 16;
@@ -449,7 +497,8 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             ok = ok && (pos >= 0) && (pos < p.rows_per_seq);
             src = (long)m + tap - 1;
         }
-        load16(p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0), ra);
+        fulla = (k + 16 <= p.K);
+        load16(p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0), fulla, ra);
         oka = ok;
     };
     // TAP3: chunk kc of the centre rows (LDS rows 1..128) and, threads 0..3, of the two halo rows (LDS rows 0 and 129)
@@ -457,11 +506,11 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         const int k = kc * GB_BK + lseg * 16;
         const int m = m0 + lrow;
         oka = m < p.M;
-        load16(p.X + (oka ? (long)m : 0) * p.ldx + k, ra);
+        load16(p.X + (oka ? (long)m : 0) * p.ldx + k, true, ra);            // TAP3: Kc % 32 == 0
         if (tid < 4) {
             const long mh = (tid >> 1) ? (long)m0 + GB_BM : (long)m0 - 1;
             okh = (tid >> 1) ? ((m0 + GB_BM) % p.rows_per_seq != 0 && mh < p.M) : (m0 % p.rows_per_seq != 0);
-            load16(p.X + (okh ? mh : 0) * p.ldx + k, rh);
+            load16(p.X + (okh ? mh : 0) * p.ldx + k, true, rh);
         }
     };
     auto wait_all = [&]() {
@@ -470,11 +519,12 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         else
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
     };
-    auto swrite_row = [&](const f32x4 (&r)[4], bool ok, int ldsrow) {
+    auto swrite_row = [&](const f32x4 (&r)[4], bool ok, int ldsrow, float sc) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             f32x4 r0 = r[2 * hh], r1 = r[2 * hh + 1];
-            if (!ok) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
+            if (!ok || (hh == 1 && !fulla)) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
+            scale_rows<NS>(r0, sc); scale_rows<NS>(r1, sc);
             unsigned q[4][NS];
             split_planes<NS>(r0[0], r0[1], q[0]);
             split_planes<NS>(r0[2], r0[3], q[1]);
@@ -534,8 +584,8 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             dma_b(kc);
             gload3(kc);
             wait_all();
-            swrite_row(ra, oka, lrow + 1);
-            if (tid < 4) swrite_row(rh, okh, (tid >> 1) ? GB_BM + 1 : 0);
+            swrite_row(ra, oka, lrow + 1, xs);
+            if (tid < 4) swrite_row(rh, okh, (tid >> 1) ? GB_BM + 1 : 0, xsh);
             __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
 #pragma unroll 1
@@ -555,77 +605,22 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             dma_b(kt);
             gload(kt);
             wait_all();
-            swrite_row(ra, oka, lrow);
+            swrite_row(ra, oka, lrow, xs);
             __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             mma_tile(0);
         }
     }
 
-    const float* bias = p.bias;
-    if (bias && p.bias_group_rows > 0) bias += (long)(m0 / p.bias_group_rows) * p.ldbias;
-    float bj[2], sj[2], tj[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
-        const bool okc = col < p.N;
-        bj[j] = (bias && okc) ? bias[col] : 0.f;
-        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
-        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
-    }
-    if (p.rowmax_rows == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] * p.w_unscale + bj[j];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
-                    if (row < p.M && col < p.N) p.Y[(long)row * p.ldy + col] = v;
-                }
-            }
-    } else {
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-        float mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
-                    float v = acc[i][j][r] * p.w_unscale + bj[j];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
-                    if (row < p.M) mx[j] = fmaxf(mx[j], v);
-                }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mx[j] = fmaxf(mx[j], __shfl_xor(mx[j], 32, 64));
-        if (half == 0) {
-            red[wm * GO_BN + wn * 64 + l31] = mx[0];
-            red[wm * GO_BN + wn * 64 + 32 + l31] = mx[1];
-        }
-        __syncthreads();
-        if (tid < GO_BN) {
-            const int c = n0 + tid;
-            if (c < p.N) p.Y[(long)(m0 / p.rowmax_rows) * p.ldy + c] = fmaxf(red[tid], red[GO_BN + tid]);
-        }
-    }
+    gemm_epilogue<NS, 2, 2>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
 }
 
 template <int NS, bool TAP3>
 int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS, TAP3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS, TAP3>::LDS_BYTES));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS, TAP3>::LDS_BYTES)););
     gemm_nt_bf16_occ_kernel<NS, TAP3><<<p.nblk, GO_THREADS, GOCfg<NS, TAP3>::LDS_BYTES, st>>>(p, Ws);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
@@ -644,6 +639,7 @@ int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
 // called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
 int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->K % 8) == 0);
+    if (d->taps == 3) EV2H_CHECK_ARG((d->K % 16) == 0);       // a 16-float loader segment never straddles two taps
     GemmBP p{};
     p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = d->Y; p.ldy = d->ldy;
     p.M = d->M; p.N = d->N; p.taps = d->taps; p.Kc = d->K; p.K = d->K * d->taps;
@@ -652,6 +648,16 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
     p.rowmax_rows = d->rowmax_rows;
     p.w_unscale = d->w_unscale > 0.f ? d->w_unscale : 1.f;
+    if (d->precision == EV2H_PREC_F16X2) {
+        p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
+        p.y_amax = d->y_amax; p.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
+        p.y_scale = d->y_scale; p.y_bound_w = d->y_bound_w; p.y_bound_b = d->y_bound_b;
+        if (!p.x_amax) { p.x_amax2 = nullptr; p.y_scale = nullptr; }
+        if (p.y_scale) EV2H_CHECK_ARG(p.x_group_rows == p.y_group_rows && d->rowmax_rows == 0);
+        if (d->taps == 3 && p.x_amax) EV2H_CHECK_ARG(p.x_group_rows % d->rows_per_seq == 0);   // a sequence never straddles two scales
+    } else {
+        p.x_group_rows = p.y_group_rows = 1;
+    }
     static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
     p.debug = dbg;
     if (d->Ws && d->ws_tile_rows == 128) {   // 128-row plane images: three small workgroups per CU

@@ -24,34 +24,19 @@ struct ManoP {
 __constant__ int c_parent[NJ] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
 __constant__ int c_joint_reorder[21] = {0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20};
 
-constexpr int MANO_THREADS = 832;     // 13 waves: one vertex per thread (778), so the 145-term blend sums of a window run side by side
-
-__global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
-    __shared__ float s_pose[48];
-    __shared__ float s_R[NJ][9];
-    __shared__ float s_coef[NCOEF + 3];
-    __shared__ float s_J[NJ][3];
-    __shared__ float s_G[NJ][12];      // rows of [R | t]
-    __shared__ float s_A[NJ][12];
-    __shared__ float s_tip[5][3];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* prm = p.params + (size_t)b * p.ldp;
-    const int nc = p.c.ncomps;
-    const float* betas = prm + 3 + nc;
-    const float* transl = prm + 3 + nc + NB;
-
-    // 1. full pose = [global_orient, hands_mean + pca_coeffs @ comps]
+// Steps 1-2 of the layer, shared by mano_kernel and the debug kernel that exposes the rotation matrices:
+// 1. full pose = [global_orient, hands_mean + pca_coeffs @ comps];  2. Rodrigues (quaternion route, theta + 1e-8 inside the norm,
+// /root/reference/src/Ev2Hands/losses.py:14-51).  Contains one __syncthreads(); the caller synchronises before reading s_R.
+__device__ __forceinline__ void mano_pose_and_rotations(const ev2h_mano_consts& c, const float* prm, int tid, float* s_pose, float (*s_R)[9]) {
+    const int nc = c.ncomps;
     if (tid < 3) s_pose[tid] = prm[tid];
     else if (tid < 48) {
         const int t = tid - 3;
         float acc = 0.f;
-        for (int k = 0; k < nc; ++k) acc = __fmaf_rn(prm[3 + k], p.c.comps[k * 45 + t], acc);
-        s_pose[tid] = __fadd_rn(p.c.hands_mean[t], acc);
+        for (int k = 0; k < nc; ++k) acc = __fmaf_rn(prm[3 + k], c.comps[k * 45 + t], acc);
+        s_pose[tid] = __fadd_rn(c.hands_mean[t], acc);
     }
-    if (tid >= 64 && tid < 64 + NB) s_coef[tid - 64] = betas[tid - 64];
     __syncthreads();
-
-    // 2. Rodrigues (quaternion route, theta + 1e-8 inside the norm)
     if (tid < NJ) {
         const float x = s_pose[3 * tid], y = s_pose[3 * tid + 1], z = s_pose[3 * tid + 2];
         const float ex = x + 1e-8f, ey = y + 1e-8f, ez = z + 1e-8f;
@@ -75,6 +60,36 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
         R[7] = __fadd_rn(__fmul_rn(2.f, wx), __fmul_rn(2.f, yz));
         R[8] = __fadd_rn(__fsub_rn(__fsub_rn(w2, x2), y2), z2);
     }
+}
+
+// debug / parity: the 16 rotation matrices the layer uses for each window (tests/test_gpu_ops.py)
+__global__ __launch_bounds__(64) void mano_rotations_kernel(ev2h_mano_consts c, const float* params, int ldp, float* rot) {
+    __shared__ float s_pose[48];
+    __shared__ float s_R[NJ][9];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    mano_pose_and_rotations(c, params + (size_t)b * ldp, tid, s_pose, s_R);
+    __syncthreads();
+    for (int i = tid; i < NJ * 9; i += 64) rot[(size_t)b * NJ * 9 + i] = s_R[i / 9][i % 9];
+}
+
+constexpr int MANO_THREADS = 832;     // 13 waves: one vertex per thread (778), so the 145-term blend sums of a window run side by side
+
+__global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
+    __shared__ float s_pose[48];
+    __shared__ float s_R[NJ][9];
+    __shared__ float s_coef[NCOEF + 3];
+    __shared__ float s_J[NJ][3];
+    __shared__ float s_G[NJ][12];      // rows of [R | t]
+    __shared__ float s_A[NJ][12];
+    __shared__ float s_tip[5][3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* prm = p.params + (size_t)b * p.ldp;
+    const int nc = p.c.ncomps;
+    const float* betas = prm + 3 + nc;
+    const float* transl = prm + 3 + nc + NB;
+
+    mano_pose_and_rotations(p.c, prm, tid, s_pose, s_R);       // steps 1-2 (ends with the rotations written, not yet synchronised)
+    if (tid >= 64 && tid < 64 + NB) s_coef[tid - 64] = betas[tid - 64];
     // 4. joints of the shaped template: J = J_template + J_shape^T beta
     if (tid >= 64 && tid < 64 + 48) {
         const int t = tid - 64;
@@ -187,6 +202,14 @@ extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp
     ManoP p{};
     p.c = *c; p.params = params; p.ldp = ldp; p.verts = verts; p.joints = joints;
     mano_kernel<<<B, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_mano_rotations(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* rot, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(c && params && rot && B > 0 && c->hands_mean && c->comps);
+    EV2H_CHECK_ARG(c->ncomps >= 1 && c->ncomps <= 45 && ldp >= 3 + c->ncomps);
+    mano_rotations_kernel<<<B, 64, 0, (hipStream_t)stream>>>(*c, params, ldp, rot);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

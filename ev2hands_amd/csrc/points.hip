@@ -19,15 +19,15 @@ __device__ __forceinline__ float sqnorm3(float x, float y, float z) {
 
 // ---------------------------------------------------------------------------------------- prep
 __global__ __launch_bounds__(256) void prep_points_kernel(float* __restrict__ xyz_cm, int C, int N, int mhlnes,
-                                                          float4* __restrict__ pts4, float4* __restrict__ feat8) {
+                                                          float4* __restrict__ pts4, float4* __restrict__ feat8,
+                                                          unsigned* __restrict__ amax) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
     float* base = xyz_cm + (size_t)b * C * N;
     float f[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) f[c] = (c < C) ? base[(size_t)c * N + n] : 0.f;
-    if (mhlnes) {
+    for (int c = 0; c < 8; ++c) f[c] = (c < C && n < N) ? base[(size_t)c * N + n] : 0.f;
+    if (mhlnes && n < N) {
         // TEHNet.py:176-177: channel 2 is overwritten IN PLACE by the mean of channels 3..C-1
         float s = f[3];
         for (int c = 4; c < C; ++c) s = __fadd_rn(s, f[c]);
@@ -35,6 +35,14 @@ __global__ __launch_bounds__(256) void prep_points_kernel(float* __restrict__ xy
         f[2] = s;
         base[(size_t)2 * N + n] = s;
     }
+    if (amax) {                          // range record of the window's input channels (f16x2, ev2hands_hip.h "Range records")
+        unsigned m = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m = max(m, __float_as_uint(f[c]) & 0x7fffffffu);
+        m = wave_max_u32_dpp(m);
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(&amax[b], m);
+    }
+    if (n >= N) return;
     pts4[(size_t)b * N + n] = make_float4(f[0], f[1], f[2], sqnorm3(f[0], f[1], f[2]));
     feat8[((size_t)b * N + n) * 2 + 0] = make_float4(f[0], f[1], f[2], f[3]);
     feat8[((size_t)b * N + n) * 2 + 1] = make_float4(f[4], f[5], f[6], f[7]);
@@ -200,7 +208,8 @@ constexpr int NN_PTS_PER_WG = 256;
 __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __restrict__ pts1, const float4* __restrict__ pts2,
                                                               int N1, int N2, const float* __restrict__ feat2, int ldf2, int D,
                                                               float* __restrict__ out, int ldo,
-                                                              int32_t* __restrict__ nn_idx, float* __restrict__ nn_w) {
+                                                              int32_t* __restrict__ nn_idx, float* __restrict__ nn_w,
+                                                              unsigned* __restrict__ amax) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* s2 = reinterpret_cast<float4*>(smem_raw);                 // [N2]
     int* sidx = reinterpret_cast<int*>(s2 + N2);                       // [256][3]
@@ -248,6 +257,7 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
     if (!out) return;
     // each wave interpolates 64 of the block's points, lanes across channels (float4)
     const int D4 = D >> 2;
+    unsigned am = 0u;
     for (int t = wave * 64; t < wave * 64 + 64; ++t) {
         const int nn = blockIdx.x * NN_PTS_PER_WG + t;
         if (nn >= N1) break;
@@ -266,19 +276,25 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
             r.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(bq.z, w1)), __fmul_rn(cq.z, w2));
             r.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(bq.w, w1)), __fmul_rn(cq.w, w2));
             o[c] = r;
+            am = max(max(am, __float_as_uint(r.x) & 0x7fffffffu), max(__float_as_uint(r.y) & 0x7fffffffu,
+                     max(__float_as_uint(r.z) & 0x7fffffffu, __float_as_uint(r.w) & 0x7fffffffu)));
         }
+    }
+    if (amax) {                          // range record of the interpolated rows (f16x2)
+        am = wave_max_u32_dpp(am);
+        if (lane == 0 && am) atomicMax(&amax[b], am);
     }
 }
 
 }  // namespace
 
 // ======================================================================================== C ABI
-extern "C" int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8,
+extern "C" int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8, uint32_t* amax,
                                 ev2h_stream_t stream) {
     EV2H_CHECK_ARG(xyz_cm && pts4 && feat8);
     EV2H_CHECK_ARG(B > 0 && N > 0 && C >= 4 && C <= 8);
     dim3 grid(ceil_div(N, 256), B);
-    prep_points_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(xyz_cm, C, N, mhlnes, (float4*)pts4, (float4*)feat8);
+    prep_points_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(xyz_cm, C, N, mhlnes, (float4*)pts4, (float4*)feat8, amax);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
@@ -301,14 +317,12 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     hipStream_t st = (hipStream_t)stream;
     const float4* p = (const float4*)pts4;
     if (N > 2048) {   // > 32 KiB of points: raise the dynamic-LDS limit once
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDevice attr_set{};
+        EV2H_ONCE_PER_DEVICE(attr_set,
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-            attr_set = true;
-        }
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16)););
     }
     if (N <= 256) fps_kernel<1><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 512) fps_kernel<2><<<grid, 256, lds, st>>>(p, N, jobs);
@@ -325,7 +339,7 @@ extern "C" int ev2h_fps(const float* pts4, int B, int N, int S, const int64_t* i
     return ev2h_fps_multi(pts4, B, N, 1, &S, &init, &idx, &ctr4, stream);
 }
 
-extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const float* radius,
+extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const double* radius,
                                const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts4 && ctr4 && radius && nsample && gidx);
     EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 8192 && S > 0 && nrad >= 1 && nrad <= 3);
@@ -333,20 +347,18 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     a.nrad = nrad;
     for (int i = 0; i < nrad; ++i) {
         EV2H_CHECK_ARG(gidx[i] && nsample[i] > 0);
-        // `radius ** 2` is evaluated in python double and compared against fp32 distances
-        a.r2[i] = (float)((double)radius[i] * (double)radius[i]);
+        // `radius ** 2` is evaluated in Python double precision, then rounded to fp32 for the comparison (pointnet2_utils.py:102)
+        a.r2[i] = (float)(radius[i] * radius[i]);
         a.K[i] = nsample[i];
         a.gidx[i] = gidx[i];
     }
     a.cnt = cnt;
     dim3 grid(ceil_div(S, BALL_CTR_PER_WG), B);
     if (N > 4096) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static PerDevice attr_set{};
+        EV2H_ONCE_PER_DEVICE(attr_set,
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-            attr_set = true;
-        }
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16)););
     }
     ball_query_kernel<<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
                                                                                        N, S, a);
@@ -355,7 +367,7 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
 }
 
 extern "C" int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, int B, int N1, int N2, const float* feat2,
-                                    int ldf2, int D, float* out, int ldo, int32_t* nn_idx, float* nn_w,
+                                    int ldf2, int D, float* out, int ldo, int32_t* nn_idx, float* nn_w, uint32_t* out_amax,
                                     ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts1_4 && pts2_4);
     EV2H_CHECK_ARG(B > 0 && N1 > 0 && N2 >= 3 && N2 <= 4096);
@@ -363,7 +375,7 @@ extern "C" int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, in
     dim3 grid(ceil_div(N1, NN_PTS_PER_WG), B);
     const size_t lds = (size_t)N2 * sizeof(float4) + NN_PTS_PER_WG * 3 * (sizeof(int) + sizeof(float));
     three_nn_interp_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const float4*)pts1_4, (const float4*)pts2_4, N1, N2, feat2,
-                                                                    ldf2, D, out, ldo, nn_idx, nn_w);
+                                                                    ldf2, D, out, ldo, nn_idx, nn_w, out_amax);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -247,13 +247,11 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_mlp_max_kernel(SaP p) {
 template <int C1, int C2, int C3>
 int launch_sa(const SaP& p, hipStream_t st) {
     using Cfg = SaCfg<C1, C2, C3>;
-    static bool attr_set = false;
+    static PerDevice attr_set{};
     const int lds = Cfg::LDS_FLOATS * (int)sizeof(float);
-    if (!attr_set) {
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_kernel<C1, C2, C3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     sa_mlp_max_kernel<C1, C2, C3><<<p.nblk, SA_THREADS, lds, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

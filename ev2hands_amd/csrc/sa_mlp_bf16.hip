@@ -32,6 +32,10 @@ struct SaBP {
     const int32_t* cnt; int cnt_ld;       // optional distinct-neighbour counts (ev2h_sa_desc.cnt)
     float u2, u3;                         // power-of-two unscale factors of the W2s / W3s planes (ev2h_sa_desc.w2_unscale)
     int per_xcd;                          // resident variant: groups per XCD (multiple of 8); nblk is a multiple of 8
+    // f16x2 activation range (ev2h_sa_desc; NULL p1_scale = off)
+    const float* p1_scale; const unsigned* p1_amax;   // per window: power of two the P1 table was stored with, max |stored P1|
+    float w1x_norm, dmax, w2_norm, b2_max;
+    unsigned* out_amax;                    // per window: atomicMax of |out|
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -140,6 +144,20 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 
     const float4 ctr = p.ctr4[gg];
     const int32_t* gi = p.gidx + (size_t)gg * p.K;
+    // f16x2 range: with P1' = s1 P1 (table stored scaled) and d' = s1 d the layer-1 output is H1' = s1 H1 <= a1 + s1 |W1x|_1 dmax
+    // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
+    // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
+    float s1 = 1.f, c2 = p.u2, c3 = p.u3;
+    if constexpr (NS == 2) {
+        if (p.p1_scale) {
+            s1 = p.p1_scale[b];
+            const float inv_s1 = pow2_inverse(s1);
+            const float bh1 = __uint_as_float(p.p1_amax[b]) + s1 * (p.w1x_norm * p.dmax);
+            const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bh1 * inv_s1, p.b2_max)));
+            c2 = p.u2 * s2 * inv_s1;
+            c3 = p.u3 * pow2_inverse(s2);
+        }
+    }
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
     // workgroup's longest group (DMA pieces and barriers), without computing.
@@ -178,7 +196,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
         const int idx = gi[strip * 32 + l31];
         const float4 q = p.pts4[(size_t)b * p.Npts + idx];
-        const float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
+        float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
+        if constexpr (NS == 2) { dx *= s1; dy *= s1; dz *= s1; }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
         const float4* prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
         f32x4 raw[4];
 #pragma unroll
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j = 0; j < 4; ++j) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 32 * t + 8 * j + 4 * half);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h2[t][4 * j + e] = bv[e];
+                for (int e = 0; e < 4; ++e) h2[t][4 * j + e] = (NS == 2) ? bv[e] * s1 : bv[e];
             }
 
 #ifdef EV2H_SAB_TIMELINE
@@ -222,8 +241,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
                 unsigned lo[NS], hi[NS];
-                split_planes<NS>(relu_bits(v[0]), relu_bits(v[1]), lo);
-                split_planes<NS>(relu_bits(v[2]), relu_bits(v[3]), hi);
+                if constexpr (NS == 2) {
+                    split_planes<NS>(relu_sat_f16(v[0]), relu_sat_f16(v[1]), lo);
+                    split_planes<NS>(relu_sat_f16(v[2]), relu_sat_f16(v[3]), hi);
+                } else {
+                    split_planes<NS>(relu_bits(v[0]), relu_bits(v[1]), lo);
+                    split_planes<NS>(relu_bits(v[2]), relu_bits(v[3]), hi);
+                }
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 0] = lo[s];
@@ -273,7 +297,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 unsigned o[NS];
-                split_planes<NS>(relu_bits(h2[t][2 * k] * p.u2), relu_bits(h2[t][2 * k + 1] * p.u2), o);
+                if constexpr (NS == 2) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
+                else split_planes<NS>(relu_bits(h2[t][2 * k] * c2), relu_bits(h2[t][2 * k + 1] * c2), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
@@ -340,10 +365,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         STAMP(37);
     }
 
+    unsigned am = 0u;
 #pragma unroll
     for (int u = 0; u < T3; ++u) {
         const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
-        if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v * p.u3 + p.b3[32 * u + l31], 0.f);
+        if (valid && half == 0) {
+            const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
+            p.out[(size_t)g * p.ldo + 32 * u + l31] = o;
+            am = max(am, __float_as_uint(o));
+        }
+    }
+    if constexpr (NS == 2) {
+        if (p.out_amax) {
+            am = wave_max_u32_dpp(am);
+            if (lane == 0 && am) atomicMax(&p.out_amax[b], am);
+        }
     }
     if constexpr (!RES) break;
   }
@@ -355,13 +391,16 @@ int launch_sab(SaBP p, hipStream_t st) {
     static const bool streamed_only = getenv("EV2H_SA_STREAMED") != nullptr;      // A/B switch for the resident variant
     if constexpr (Cfg::FITS_RESIDENT) {
         if (!streamed_only) {
-            static int wg_per_cu = 0;
+            static PerDevice wg_slot{};                   // per device: 0 = not queried yet, else workgroups per CU
+            std::atomic<int>& wg = wg_slot.cur();
+            int wg_per_cu = wg.load(std::memory_order_acquire);
             if (!wg_per_cu) {
                 auto k = sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true>;
                 EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::RES_LDS_BYTES));
                 int n = 0;
                 EV2H_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SAB_THREADS, Cfg::RES_LDS_BYTES));
                 wg_per_cu = n > 0 ? n : 1;
+                wg.store(wg_per_cu, std::memory_order_release);
             }
             const int ngroups = p.B * p.S;
             const int want = 256 * wg_per_cu;                                   // one resident wave of workgroups
@@ -372,12 +411,10 @@ int launch_sab(SaBP p, hipStream_t st) {
             return EV2H_OK;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES));
-        attr_set = true;
-    }
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
     sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
@@ -411,6 +448,14 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
+    if (d->precision == EV2H_PREC_F16X2) {
+        p.out_amax = d->out_amax;
+        if (d->p1_scale) {
+            EV2H_CHECK_ARG(d->p1_amax && d->dmax > 0.f && d->w1x_norm >= 0.f && d->w2_norm >= 0.f && d->b2_max >= 0.f);
+            p.p1_scale = d->p1_scale; p.p1_amax = d->p1_amax;
+            p.w1x_norm = d->w1x_norm; p.dmax = d->dmax; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);
     if (d->precision == EV2H_PREC_F16X2) return dispatch_sab<2>(p, d->C1, d->C2, d->C3, st);

@@ -150,10 +150,11 @@ class TEHNet(nn.Module):
         init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
 
         pw = self.packed(device)
-        native = all(isinstance(mano_hands[s], ManoHand) for s in ("left", "right"))
-        if not native:
-            raise TypeError("mano_hands must come from ev2hands_amd.create_mano_layers (ManoHand objects)")
-        cl, cr = mano_hands["left"].consts(), mano_hands["right"].consts()
+        # hand models from ev2hands_amd.create_mano_layers run inside ev2h_forward; any other object with the reference adapter's
+        # interface (model/utils.py:14-31: .shapedirs, .faces, __call__(global_orient, hand_pose, betas, transl) -> .vertices,
+        # .joints) is called with the regressed parameters exactly as TEHNet.py:92-105 does
+        native = {s: isinstance(mano_hands[s], ManoHand) for s in ("left", "right")}
+        consts = {s: (C.byref(mano_hands[s].consts()) if native[s] else None) for s in ("left", "right")}
 
         f32 = dict(device=device, dtype=torch.float32)
         logits = torch.empty(B, 4, N, **f32)
@@ -169,16 +170,21 @@ class TEHNet(nn.Module):
         nbytes = L.ev2h_workspace_bytes(B, N)
         ws = self.workspace(nbytes, device)
         with torch.cuda.device(device):
-            _lib.check(L.ev2h_forward(C.byref(pw.struct), C.byref(cl), C.byref(cr), x.data_ptr(), B, Cin, N, self.mhlnes,
+            _lib.check(L.ev2h_forward(C.byref(pw.struct), consts["left"], consts["right"], x.data_ptr(), B, Cin, N, self.mhlnes,
                                       init_dev.data_ptr(), C.byref(out), ws.data_ptr(), nbytes, _lib.stream_handle()),
                        "ev2h_forward")
         res = {"class_logits": logits}
         npose = self.n_pose_params
         for h, side in enumerate(("left", "right")):
             p = params[h]
-            d = {"vertices": verts[h], "j3d": joints[h],
-                 "global_orient": p[:, :3], "hand_pose": p[:, 3:3 + npose], "betas": p[:, 3 + npose:-3],
-                 "transl": p[:, -3:]}
+            d = {"global_orient": p[:, :3], "hand_pose": p[:, 3:3 + npose], "betas": p[:, 3 + npose:-3], "transl": p[:, -3:]}
+            if native[side]:
+                d = {"vertices": verts[h], "j3d": joints[h], **d}
+            else:
+                hd = mano_hands[side].shapedirs.device                       # TEHNet.py:92-105
+                d = {k: v.to(hd) for k, v in d.items()}
+                o = mano_hands[side](**d)
+                d = {"vertices": o.vertices, "j3d": o.joints, **d}
             d["faces"] = np.tile(mano_hands[side].faces, (B, 1, 1))       # eval only (TEHNet.py:109-110)
             res[side] = d
         self._last_shape = (B, N)

@@ -22,8 +22,18 @@ def pack_points(xyz: torch.Tensor) -> torch.Tensor:
     cm[:, :3] = xyz.permute(0, 2, 1)
     pts4 = torch.empty(B, N, 4, device=xyz.device, dtype=torch.float32)
     feat8 = torch.empty(B, N, 8, device=xyz.device, dtype=torch.float32)
-    _lib.check(_lib.lib().ev2h_prep_points(cm.data_ptr(), B, 4, N, 0, pts4.data_ptr(), feat8.data_ptr(), _st()), "prep")
+    _lib.check(_lib.lib().ev2h_prep_points(cm.data_ptr(), B, 4, N, 0, pts4.data_ptr(), feat8.data_ptr(), None, _st()), "prep")
     return pts4
+
+
+def range_record(groups: int, device) -> torch.Tensor:
+    """A zeroed F16X2 range record (uint32 bit patterns of max |value| per group, include/ev2hands_hip.h "Range records")."""
+    return torch.zeros(groups, dtype=torch.int32, device=device)
+
+
+def range_values(rec: torch.Tensor) -> torch.Tensor:
+    """The maxima a range record holds, as float32."""
+    return rec.view(torch.float32)
 
 
 def farthest_point_sample(xyz: torch.Tensor, npoint: int, init: torch.Tensor | None = None) -> torch.Tensor:
@@ -50,7 +60,7 @@ def query_ball_point(radius, nsample, xyz: torch.Tensor, new_xyz: torch.Tensor, 
     outs = [torch.empty(B, S, k, device=xyz.device, dtype=torch.int32) for k in ks]
     cnt = torch.empty(B, S, len(ks), device=xyz.device, dtype=torch.int32)
     n = len(ks)
-    r_arr = (C.c_float * n)(*[float(r) for r in radii])
+    r_arr = (C.c_double * n)(*[float(r) for r in radii])
     k_arr = (C.c_int * n)(*ks)
     g_arr = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
     _lib.check(_lib.lib().ev2h_ball_query(pts4.data_ptr(), ctr4.data_ptr(), B, N, S, n, r_arr, k_arr, g_arr, cnt.data_ptr(),
@@ -61,8 +71,9 @@ def query_ball_point(radius, nsample, xyz: torch.Tensor, new_xyz: torch.Tensor, 
     return (res, cnt) if return_counts else res
 
 
-def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Tensor):
-    """pointnet2_utils.py:296-303.  xyz1 [B,N,3], xyz2 [B,S,3], feat2 [B,S,D] -> (interp [B,N,D], idx, weight)."""
+def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Tensor, out_amax: torch.Tensor | None = None):
+    """pointnet2_utils.py:296-303.  xyz1 [B,N,3], xyz2 [B,S,3], feat2 [B,S,D] -> (interp [B,N,D], idx, weight).
+    out_amax: optional range record [B] of the interpolated rows."""
     B, N, _ = xyz1.shape
     S, D = xyz2.shape[1], feat2.shape[2]
     p1, p2 = pack_points(xyz1), pack_points(xyz2)
@@ -71,13 +82,15 @@ def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Te
     idx = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int32)
     w = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
     _lib.check(_lib.lib().ev2h_three_nn_interp(p1.data_ptr(), p2.data_ptr(), B, N, S, f2.data_ptr(), D, D, out.data_ptr(), D,
-                                               idx.data_ptr(), w.data_ptr(), _st()), "ev2h_three_nn_interp")
+                                               idx.data_ptr(), w.data_ptr(), _lib.ptr(out_amax), _st()), "ev2h_three_nn_interp")
     return out, idx.long(), w
 
 
 def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=None, post_shift=None, taps=1,
-          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32", presplit: bool = True, w_image=None, w_tile_rows: int = 128) -> torch.Tensor:
-    """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1]."""
+          rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32", presplit: bool = True, w_image=None, w_tile_rows: int = 128,
+          x_amax=None, x_amax2=None, x_group_rows=0, y_amax=None, y_group_rows=0, y_scale=None, y_bound_w=0.0, y_bound_b=0.0) -> torch.Tensor:
+    """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1].
+    x_amax .. y_bound_b: the F16X2 range arguments of ev2h_gemm_desc (range_record tensors)."""
     M, ldx = X.shape
     N, ldw = W.shape
     K = (ldx if K is None else K)
@@ -93,6 +106,9 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     d.post_scale, d.post_shift = _lib.ptr(post_scale), _lib.ptr(post_shift)
     d.taps, d.rows_per_seq, d.rowmax_rows = taps, rows_per_seq, rowmax_rows
     d.precision = _lib.PREC[precision]
+    d.x_amax, d.x_amax2, d.x_group_rows = _lib.ptr(x_amax), _lib.ptr(x_amax2), x_group_rows
+    d.y_amax, d.y_group_rows = _lib.ptr(y_amax), y_group_rows
+    d.y_scale, d.y_bound_w, d.y_bound_b = _lib.ptr(y_scale), y_bound_w, y_bound_b
     keep = None
     d.ws_tile_rows = w_tile_rows
     if w_image is not None:
@@ -117,10 +133,13 @@ def make_w_image(W: torch.Tensor, precision: str, rows: int = 128):
     return torch.from_numpy(img).to(W.device), u          # (device image, power-of-two unscale)
 
 
-def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None) -> torch.Tensor:
+def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None,
+               p1_scale=None, p1_amax=None, dmax: float = 0.0, out_amax=None) -> torch.Tensor:
     """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3].
     W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); 16-bit tile images are built here when needed.
-    cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped."""
+    cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped.
+    p1_scale [B] float32 / p1_amax [B] range record / dmax / out_amax: the F16X2 range arguments of ev2h_sa_desc (P1 then
+    holds p1_scale[b] * table)."""
     B, Npts, C1 = P1.shape
     S, K = gidx.shape[1], gidx.shape[2]
     C3 = W3.shape[0]
@@ -134,6 +153,12 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     if cnt is not None:
         assert cnt.dtype == torch.int32 and cnt.is_contiguous() and cnt.shape == (B, S)
         d.cnt, d.cnt_ld = cnt.data_ptr(), 1
+    d.out_amax = _lib.ptr(out_amax)
+    if p1_scale is not None:
+        d.p1_scale, d.p1_amax, d.dmax = p1_scale.data_ptr(), p1_amax.data_ptr(), dmax
+        d.w1x_norm = float(W1x[:, :3].abs().sum(1).max())
+        d.w2_norm = float(W2[:C2].abs().sum(1).max())
+        d.b2_max = float(b2[:C2].abs().max())
     keep = []
     if precision != "f32":
         from .pack import NS_OF, sa_bf16_images
@@ -145,13 +170,28 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     return out
 
 
-def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor):
+def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor, hf_amax: torch.Tensor | None = None):
     """TEHNet.py:13-27 for both hands.  logits_pm [B,N,4], query_pm [2,B,N,256], value_pm [B,N,256]
-    -> (sim [B,2,4,256], hf8 [2,B,N,8])."""
+    -> (sim [B,2,4,256], hf8 [2,B,N,8]).  hf_amax: optional range records [2,B] of the context features."""
     B, N, _ = logits_pm.shape
     sim = torch.empty(B, 2, 4, 256, device=logits_pm.device, dtype=torch.float32)
     hf8 = torch.empty(2, B, N, 8, device=logits_pm.device, dtype=torch.float32)
     L = _lib.lib()
     _lib.check(L.ev2h_attn_sim(logits_pm.data_ptr(), query_pm.data_ptr(), 256, B * N * 256, B, N, sim.data_ptr(), _st()), "sim")
-    _lib.check(L.ev2h_attn_context(sim.data_ptr(), value_pm.data_ptr(), 256, B, N, hf8.data_ptr(), _st()), "ctx")
+    _lib.check(L.ev2h_attn_context(sim.data_ptr(), value_pm.data_ptr(), 256, B, N, hf8.data_ptr(), _lib.ptr(hf_amax), B, _st()), "ctx")
     return sim, hf8
+
+
+def mano_rotations(theta: torch.Tensor) -> torch.Tensor:
+    """Axis-angle vectors [M,16,3] -> the rotation matrices [M,16,3,3] the MANO kernel computes for them (ev2h_mano_rotations with
+    an identity pose basis and a zero mean pose, so that the full pose IS theta).  Parity hook for losses.py:14-51."""
+    M = theta.shape[0]
+    dev = theta.device
+    prm = theta.reshape(M, 48).to(torch.float32).contiguous()
+    mean = torch.zeros(45, device=dev, dtype=torch.float32)
+    comps = torch.eye(45, device=dev, dtype=torch.float32).contiguous()
+    c = _lib.ManoConsts()
+    c.hands_mean, c.comps, c.ncomps = mean.data_ptr(), comps.data_ptr(), 45
+    rot = torch.empty(M, 16, 3, 3, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().ev2h_mano_rotations(C.byref(c), prm.data_ptr(), 48, M, rot.data_ptr(), _st()), "ev2h_mano_rotations")
+    return rot

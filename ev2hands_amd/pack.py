@@ -277,12 +277,20 @@ class PackedWeights:
             br.W3 = self._dev(n + ".W3", _pad(Ws[2], C3, _up(C2, 8)))
             br.b3 = self._dev(n + ".b3", bs[2])
             br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, K, float(r)
+            # F16X2 range bounds (ev2h_sa_desc): rounded up a little so that fp32 rounding can never make a bound too small
+            br.w1x_norm = float(np.abs(Ws[0][:, nfeat:]).sum(1).max()) * (1 + 1e-6)
+            br.w2_norm = float(np.abs(Ws[1]).sum(1).max()) * (1 + 1e-6)
+            br.b2_max = float(np.abs(bs[1]).max()) * (1 + 1e-6)
             if self.ns:
                 i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(Ws[1], Ws[2], self.ns)
                 br.W2s = self._dev_bytes(n + ".W2s", i2)
                 br.W3s = self._dev_bytes(n + ".W3s", i3)
-        m.W1f = self._dev(prefix + ".W1f", np.concatenate(W1f, 0))
-        m.b1 = self._dev(prefix + ".b1", np.concatenate(b1, 0))
+        W1f_all, b1_all = np.concatenate(W1f, 0), np.concatenate(b1, 0)
+        m.W1f = self._dev(prefix + ".W1f", W1f_all)
+        m.b1 = self._dev(prefix + ".b1", b1_all)
+        m.w1f_unscale = plane_unscale(W1f_all, self.ns)        # the table GEMM splits W1f / w1f_unscale on the fly
+        m.w1f_norm = float(np.abs(W1f_all).sum(1).max()) * (1 + 1e-6)
+        m.b1_max = float(np.abs(b1_all).max()) * (1 + 1e-6)
 
     def nbytes(self) -> int:
         return sum(t.numel() * 4 for t in self._keep)

@@ -226,11 +226,30 @@ def synth_cloud_events(B: int, C: int, N: int, seed: int = 0) -> torch.Tensor:
     return torch.from_numpy(out)
 
 
+def synth_cloud_lattice(B: int, C: int, N: int, seed: int = 0) -> torch.Tensor:
+    """Distribution L (stress case for the discrete selections): N distinct points of the cubic lattice 0.02 * Z^3 inside
+    [-0.24, 0.24]^3.  Lattice vectors of squared length 25, 100, 400, 1600 (x 0.02^2) put many point pairs at EXACTLY the
+    ball-query radii 0.1, 0.2, 0.4, 0.8 -- where the fp32 rounding of the matmul-form distance decides `d > r*r`
+    (pointnet2_utils.py:100-102) -- and give every query point several equidistant 3-NN candidates (:296-298) and FPS ties
+    (:83).  Feature channels as in distribution U."""
+    if N > 25 ** 3:
+        raise ValueError("lattice cloud holds at most 15625 distinct points")
+    out = np.zeros((B, C, N), dtype=np.float32)
+    for b in range(B):
+        order = np.argsort(hash_uniform(f"cloudL/{b}", (25 ** 3,), seed), kind="stable")[:N]
+        k = np.stack([order // 625, (order // 25) % 25, order % 25], 0).astype(np.float64) - 12.0
+        out[b, :3] = (k * 0.02).astype(np.float32)
+        out[b, 3:] = (hash_uniform(f"cloudL/{b}/f", (C - 3, N), seed) * 2 - 1).astype(np.float32)
+    return torch.from_numpy(out)
+
+
 def synth_cloud(kind: str, B: int, C: int, N: int, seed: int = 0) -> torch.Tensor:
     if kind == "U":
         return synth_cloud_uniform(B, C, N, seed)
     if kind == "E":
         return synth_cloud_events(B, C, N, seed)
+    if kind == "L":
+        return synth_cloud_lattice(B, C, N, seed)
     raise ValueError(kind)
 
 
@@ -281,3 +300,48 @@ def synth_mano_assets(side: str, seed: int = 0) -> dict:
         "faces": faces.astype(np.int64),
         "parents": list(MANO_PARENTS),
     }
+
+
+def rescale_hidden(sd: dict, alpha: float) -> "OrderedDict":
+    """Checkpoint whose hidden activations are `alpha` times those of `sd` while the network function is unchanged
+    (ReLU is positively homogeneous): every eval-BatchNorm's weight and bias are multiplied by alpha, and the columns of the next
+    convolutions / linears that read such a scaled tensor are divided by alpha.  Raw inputs (coordinates, input channels, relative
+    xyz) keep their columns; `*_query_conv.5` keeps its scale because the attention softmax (TEHNet.py:22-23) is not homogeneous in
+    the query; the final layers (classifier.4, mano_regressor.4) divide their inputs only, so the outputs are the original ones.
+    Test helper for the range handling of the f16x2 arithmetic (hidden activations far outside the fp16 range)."""
+    a = float(alpha)
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+
+    def raw_cols(key: str, width: int):
+        """input columns of conv `key` that carry raw (unscaled) inputs"""
+        if key.startswith(("sa1.conv_blocks.",)) and key.split(".")[3] == "0":
+            return slice(0, width)                                        # [features, dx]: all raw
+        if key.startswith("sa2.conv_blocks.") and key.split(".")[3] == "0":
+            return slice(320, width)                                      # [l1_points | dx]
+        if key.startswith("sa3.mlp_convs.0."):
+            return slice(0, 3)                                            # [xyz | l2_points]
+        for side in ("left", "right"):
+            p = f"{side}_mano_regressor."
+            if key.startswith(p + "sa1.conv_blocks.") and key.split(".")[4] == "0":
+                return slice(4, width)                                    # [hand features (scaled) | dx]
+            if key.startswith(p + "sa2.mlp_convs.0."):
+                return slice(0, 3)
+        return slice(0, 0)
+
+    for k in list(out.keys()):
+        if k.endswith("num_batches_tracked"):
+            continue
+        v = out[k]
+        is_bn_affine = (".bn_blocks." in k or ".mlp_bns." in k or k.startswith("classifier.2.") or "_query_conv.2." in k
+                        or ".mano_regressor.2." in k) and k.endswith((".weight", ".bias"))
+        if is_bn_affine:
+            out[k] = v * a
+        elif k.endswith(".weight") and v.dim() >= 2 and not ("_query_conv.5." in k):
+            w = v.clone()
+            keep = raw_cols(k, w.shape[1])
+            scaled = torch.ones(w.shape[1], dtype=torch.bool)
+            scaled[keep] = False
+            shape = (1, -1) + (1,) * (w.dim() - 2)
+            factor = torch.where(scaled, torch.tensor(1.0 / a, dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64))
+            out[k] = (w.double() * factor.view(shape)).to(w.dtype)
+    return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 2
+#define EV2H_ABI_VERSION 3
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -44,6 +44,14 @@ typedef void* ev2h_stream_t; /* hipStream_t */
 #define EV2H_PREC_F16X2 2
 #define EV2H_PREC_BF16X3 3
 
+/* Range records (EV2H_PREC_F16X2).  fp16 planes overflow at 65504, so every tensor that a contraction reads in F16X2 mode has a
+ * "range record": uint32 [groups], the IEEE-754 bit pattern of max|value| over each group of rows (a group = the rows of one
+ * event window), maintained with integer atomicMax by whichever kernels write the tensor (y_amax / out_amax / amax arguments;
+ * the caller zeroes the records first).  A consumer scales each group by an exact power of two derived from the record
+ * (x_amax / p1_amax arguments) before splitting, and multiplies the accumulated products back, so no plane can overflow
+ * whatever the checkpoint or input magnitudes are, and a window's results never depend on the other windows of a batch.
+ * NULL records switch the scaling off (operands are then split as they are and must stay below 65504). */
+
 /* ---- library ------------------------------------------------------------------------------- */
 int ev2h_abi_version(void);
 const char* ev2h_last_error(void);
@@ -56,7 +64,8 @@ void ev2h_struct_sizes(size_t out[6]);
 /* [B,C,N] channel-major input -> pts4 [B][N][4] = (x, y, z, (x*x+y*y)+z*z) and feat8 [B][N][8]
  * (the C input channels, zero padded).  mhlnes != 0 reproduces TEHNet.py:176-177, including the
  * in-place overwrite of input channel 2. */
-int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8, ev2h_stream_t stream);
+int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, float* pts4, float* feat8, uint32_t* feat_amax,
+                     ev2h_stream_t stream);       /* feat_amax: optional range record [B] of the input channels */
 
 /* farthest_point_sample, model/pointnet2_utils.py:63-84.  init [B] int64 start indices (the
  * reference draws them with torch.randint on the host, :75).  Writes idx [B][S] and the selected
@@ -68,15 +77,19 @@ int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const int* S, con
 
 /* query_ball_point, model/pointnet2_utils.py:87-107, for up to 3 radii of one centroid set in one
  * pass.  radius / nsample / gidx are HOST arrays of length nrad; gidx[i] is a device buffer
- * [B][S][nsample[i]] int32; cnt (optional, device) [B][S][nrad] receives min(#in-radius, nsample). */
-int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const float* radius,
+ * [B][S][nsample[i]] int32; cnt (optional, device) [B][S][nrad] receives min(#in-radius, nsample).
+ * radius is DOUBLE: the reference compares fp32 distances with `radius ** 2` evaluated in Python double precision and then
+ * rounded to fp32 (:102); squaring an fp32-rounded radius gives a threshold one ulp higher for 0.1 and 0.2, which flips
+ * points that lie exactly on the radius. */
+int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const double* radius,
                     const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream);
 
 /* 3-NN inverse-distance interpolation, model/pointnet2_utils.py:296-303.  pts1 [B][N1][4] are the
  * query points, pts2 [B][N2][4] the known points with features feat2 [B][N2][ldf2] (first D used).
  * out [B][N1][ldo] (first D written; may be NULL), nn_idx / nn_w [B][N1][3] optional. */
 int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, int B, int N1, int N2, const float* feat2, int ldf2,
-                         int D, float* out, int ldo, int32_t* nn_idx, float* nn_w, ev2h_stream_t stream);
+                         int D, float* out, int ldo, int32_t* nn_idx, float* nn_w, uint32_t* out_amax, ev2h_stream_t stream);
+                         /* out_amax: optional range record [B] of the interpolated rows */
 
 /* ---- dense layers ------------------------------------------------------------------------------ */
 /* Y[m][n] = post( relu?( sum_{t<taps} sum_{k<K} X[m + t - (taps==3)][k] * W[n][t*K + k] + bias[n] ) )
@@ -103,6 +116,17 @@ typedef struct ev2h_gemm_desc {
     float w_unscale;             /* 16-bit precisions: W is used as W / w_unscale (Ws holds those planes) and the product is
                                     multiplied by w_unscale before the bias; a power of two chosen by the host so that the
                                     fp16 planes of small weights are not subnormal (pack.py: plane_unscale).  0 = 1.      */
+    /* F16X2 activation range (ignored by the other precisions; see "Range records" below).  All optional. */
+    const uint32_t* x_amax;      /* [ceil(M / x_group_rows)] range record of X: rows of group g are multiplied by the power of   */
+    const uint32_t* x_amax2;     /* two that puts max(x_amax[g], x_amax2[g]) in [2^14, 2^15) before the fp16 split (x_amax2:     */
+    int x_group_rows;            /* second source of a concatenated X, may be NULL); products are multiplied back.  taps == 3:   */
+                                 /* x_group_rows must be a multiple of rows_per_seq.                                             */
+    uint32_t* y_amax;            /* [..] range record of Y, updated with atomicMax (zero it before the first producer runs);      */
+    int y_group_rows;            /* groups of y_group_rows OUTPUT rows (with rowmax_rows: rows of the reduced output)             */
+    float* y_scale;              /* out [ceil(M / y_group_rows)], needs x_amax and y_group_rows == x_group_rows: Y is            */
+    float y_bound_w, y_bound_b;  /* stored times the power of two s[g] with (y_bound_w * max|X_g| + y_bound_b) * s[g] in          */
+                                 /* [2^14, 2^15) -- y_bound_w >= max row L1 norm of W makes that a bound of |Y| (+ whatever the   */
+                                 /* caller adds to y_bound_b); used for the layer-1 tables of ev2h_sa_mlp_max                     */
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 
@@ -135,6 +159,18 @@ typedef struct ev2h_sa_desc {
     int cnt_ld;                  /* (ev2h_ball_query's count output); slots >= cnt repeat slot 0, so whole 32-slot
                                     strips of padding are skipped by the 16-bit kernels -- the max is unchanged.  NULL (or
                                     EV2H_PREC_F32) = process all K slots                                       */
+    /* F16X2 activation range (optional; see "Range records").  The layer-1 table arrives scaled: P1 holds s[b] * (W1f' f + b1')
+     * with the power of two p1_scale[b] = s[b] chosen by the table's producer (ev2h_gemm y_scale) such that
+     * s[b] * (max|P1_b| + w1x_norm * dmax) < 2^15, and p1_amax[b] = max|stored P1_b|.  The hidden activations of layers 1 and 2
+     * are then kept inside the fp16 range by exact per-window powers of two derived from these bounds. */
+    const float* p1_scale;       /* [B]; NULL = P1 unscaled, no range handling                                          */
+    const uint32_t* p1_amax;     /* [B]                                                                                 */
+    float w1x_norm;              /* max_c (|W1x[c][0]| + |W1x[c][1]| + |W1x[c][2]|)                                     */
+    float dmax;                  /* contract: every grouped neighbour lies within dmax of its centroid per coordinate
+                                    (the ball-query radius); hidden values are saturated at 65504 if it is broken        */
+    float w2_norm;               /* max row L1 norm of W2                                                               */
+    float b2_max;                /* max |b2|                                                                            */
+    uint32_t* out_amax;          /* [B] range record of `out` (atomicMax), optional                                     */
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
@@ -144,7 +180,9 @@ int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int ldq, size_t query_hand_stride, int B, int N, float* sim,
                   ev2h_stream_t stream);
 /* hf8[h][b*N + n][0..3] = sum_d sim[b][h][c][d] * value[b*N+n][d]; columns 4..7 are written as 0. */
-int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, ev2h_stream_t stream);
+int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax,
+                      int amax_hand_stride, ev2h_stream_t stream);
+                      /* hf_amax: optional range records, hand h at hf_amax[h * amax_hand_stride + b] */
 
 /* ---- MANO layer (manopth ManoLayer.forward behind model/utils.py:25-31) ----------------------------- */
 typedef struct ev2h_mano_consts {
@@ -162,6 +200,10 @@ typedef struct ev2h_mano_consts {
  * verts [B][778][3], joints [B][21][3] in metres (mm scaling and /1000 of utils.py:28-29 included). */
 int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, float* joints,
               ev2h_stream_t stream);
+/* Parity access: rot [B][16][9] = the rotation matrices ev2h_mano derives from params (global orientation + 15 articulated joints;
+ * axis-angle -> matrix by the formula of losses.py:14-51: quaternion route, theta + 1e-8 inside the norm).  Only hands_mean, comps
+ * and ncomps of `c` are used. */
+int ev2h_mano_rotations(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* rot, ev2h_stream_t stream);
 
 /* ---- event window -> [5, N] tensor (next row 8f-1; dataset/evaluation_stream.py:187-225, ev2hands_r.py:108-159) ---- */
 /* Per-pixel accumulation + np.nonzero-order compaction of B ragged windows.  events: device [E_total][4] float64 rows
@@ -198,9 +240,10 @@ int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, cons
 typedef struct ev2h_sa_branch {
     const float* W1x; const float* W2; const float* b2; const float* W3; const float* b3;
     int C1, C2, C3, K;
-    float radius;
+    double radius;                      /* double: see ev2h_ball_query */
     const void* W2s; const void* W3s;   /* 16-bit tile images (NULL unless precision != F32) */
     float w2_unscale, w3_unscale;       /* see ev2h_sa_desc */
+    float w1x_norm, w2_norm, b2_max;    /* F16X2 range bounds as in ev2h_sa_desc; filled by pack.py */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
@@ -210,6 +253,8 @@ typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_ut
     int npoint;
     int nbranch;
     ev2h_sa_branch br[3];
+    float w1f_unscale;            /* power-of-two plane factor of W1f (ev2h_gemm_desc.w_unscale)       */
+    float w1f_norm, b1_max;       /* F16X2 range bounds of the table: max row L1 norm of W1f, max |b1| */
 } ev2h_sa_module;
 
 typedef struct ev2h_dense {       /* one folded Conv/Linear: W [O][ldw], b [O], optional post affine    */
@@ -244,7 +289,9 @@ typedef struct ev2h_outputs {
 size_t ev2h_workspace_bytes(int B, int N);
 /* TEHNet.forward, model/TEHNet.py:168-197, for B windows of N points with C channels.
  * fps_init: device int64 [4][B] in the reference's RNG consumption order (enc.sa1, enc.sa2,
- * left.sa1, right.sa1).  workspace: device buffer of at least ev2h_workspace_bytes(B, N). */
+ * left.sa1, right.sa1).  workspace: device buffer of at least ev2h_workspace_bytes(B, N).
+ * mano_left / mano_right may be NULL: that hand's MANO layer is skipped (out->vertices / joints of the hand are not touched)
+ * and the caller applies its own hand model to out->params, as TEHNet.py:103 allows any callable. */
 int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
                  float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
                  void* workspace, size_t workspace_bytes, ev2h_stream_t stream);
@@ -255,7 +302,9 @@ int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const
 int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, int n);
 
 /* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in
- * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown. */
+ * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown.
+ * "rng.<tensor>" (e.g. "rng.l0", "rng.p1b") = the F16X2 range record of that tensor, "p1scale" = the storage scales of the
+ * four layer-1 tables [4][B] (enc.sa1, enc.sa2, left, right). */
 const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from ev2hands_amd import synth  # noqa: E402
-from oracle import mano_oracle, tehnet_oracle  # noqa: E402
+from oracle import mano_oracle, stress, tehnet_oracle  # noqa: E402
 
 REF_MODEL_DIR = "/root/reference/src/Ev2Hands/model"
 CASES = [
@@ -36,7 +36,10 @@ CASES = [
     ("U_c5_n256", "U", 5, 256, 2, 2),
     ("E_c4_n256", "E", 4, 256, 2, 3),
     ("E_c4_n8192", "E", 4, 8192, 1, 4),      # BASELINE.json config 5 window size
+    ("E_c5_n256_mhlnes", "E", 5, 256, 2, 6),  # MHLNES=1 (TEHNet.py:148,176-177): channel 2 overwritten in place (name suffix)
+    ("E_c4_n2048_ties", "E", 4, 2048, 2, 31),  # near-tie segmentation head (oracle/stress.py: near_tie_state_dict, eps 0.3)
 ]
+TIE_EPS = 0.3
 
 
 def load_reference():
@@ -65,13 +68,19 @@ def stats(t: torch.Tensor) -> np.ndarray:
 
 def run_case(pn, te, name, kind, C, N, B, seed):
     os.environ["ERPC"] = "1" if C == 5 else "0"
+    mhlnes = name.endswith("_mhlnes")
+    os.environ["MHLNES"] = "1" if mhlnes else "0"
     sd = synth.synth_state_dict(C, seed)
     net = te.TEHNet(n_pose_params=synth.MANO_CMPS)
+    assert net.mhlnes == int(mhlnes)
     net.load_state_dict(sd, strict=True)
     net.eval()
     hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
     xyz = synth.synth_cloud(kind, B, C, N, seed)
     inits = synth.fps_inits(B, N, seed)
+    if name.endswith("_ties"):
+        sd = stress.near_tie_state_dict(sd, xyz, inits, hands, TIE_EPS)
+        net.load_state_dict(sd, strict=True)
 
     # spy on the reference's selections
     rec = {"fps": [], "ball": [], "nn": []}
@@ -116,9 +125,10 @@ def run_case(pn, te, name, kind, C, N, B, seed):
         hooks.append(getattr(net, side + "_mano_regressor").register_forward_pre_hook(mkf(side)))
 
     torch.randint = spy_randint
+    xyz_ref_in = xyz.clone()                 # MHLNES=1 mutates its input (TEHNet.py:176-177): keep what the reference left behind
     try:
         with torch.no_grad():
-            ref = net(xyz.clone(), hands)
+            ref = net(xyz_ref_in, hands)
     finally:
         torch.randint = o_randint
         pn.farthest_point_sample, pn.query_ball_point = o_fps, o_ball
@@ -127,8 +137,11 @@ def run_case(pn, te, name, kind, C, N, B, seed):
 
     # our restatement must be identical here
     trace = {}
+    xyz_mine_in = xyz.clone()
     with torch.no_grad():
-        mine = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=trace)
+        mine = tehnet_oracle.tehnet_forward(sd, xyz_mine_in, hands, fps_init=inits, trace=trace, mhlnes=mhlnes)
+    assert torch.equal(xyz_mine_in, xyz_ref_in), "oracle leaves a different input behind than the reference"
+    assert torch.equal(xyz_ref_in, xyz) != mhlnes, "MHLNES must (only) mutate the input when set"
     assert torch.equal(mine["class_logits"], ref["class_logits"]), "oracle != reference (logits)"
     for side in ("left", "right"):
         for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl"):
@@ -150,6 +163,8 @@ def run_case(pn, te, name, kind, C, N, B, seed):
         "meta": np.array([B, C, N, seed], dtype=np.int64),
         "kind": np.array(kind),
         "xyz": xyz.numpy(),
+        "mhlnes": np.array(int(mhlnes)),
+        "xyz_after": xyz_ref_in.numpy() if mhlnes else np.zeros(0, dtype=np.float32),
         "fps_init": torch.stack(inits).numpy().astype(np.int32),
         "class_logits": ref["class_logits"].numpy(),
         "argmax": ref["class_logits"].argmax(1).numpy().astype(np.uint8),
@@ -174,6 +189,11 @@ def run_case(pn, te, name, kind, C, N, B, seed):
         out[side + ".params"] = feats[side + ".params"].numpy()
         out[f"unpinned.{side}.vertices"] = ref[side]["vertices"].numpy()
         out[f"unpinned.{side}.j3d"] = ref[side]["j3d"].numpy()
+    if name.endswith("_ties"):
+        m, scale = stress.margin_report(ref["class_logits"])
+        out["tie_eps"] = np.array(TIE_EPS)
+        print(f"{name}: logit scale {scale:.3g}; top-2 margin < 1e-5 scale at {float((m < 1e-5 * scale).float().mean()) * 100:.2f} % of the points, "
+              f"< 1e-6 scale at {float((m < 1e-6 * scale).float().mean()) * 100:.2f} %, exact ties {int((m == 0).sum())}")
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
@@ -186,6 +206,7 @@ def main():
     for case in CASES:
         if not only or case[0] in only:
             run_case(pn, te, *case)
+    os.environ["MHLNES"] = "0"
 
 
 if __name__ == "__main__":

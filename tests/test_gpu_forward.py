@@ -12,7 +12,7 @@ import torch
 from ev2hands_amd import synth
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_")))
 TOL = 1e-4
 
 
@@ -25,6 +25,22 @@ def rel(a, b):
     a = torch.as_tensor(a).detach().cpu().double()
     b = torch.as_tensor(b).detach().cpu().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def nn_mismatches(query, known, got, want):
+    """3-NN parity up to ties.  query [B,N,3], known [B,S,3] coordinates, got / want [B,N,3] neighbour indices.  The reference
+    takes the first three of `dists.sort(dim=-1)` (pointnet2_utils.py:297-298); torch.sort is not stable, so among candidates at
+    EXACTLY the same distance (duplicated sample points, lattice-like coordinates) its choice is implementation-defined (the
+    AVX-512 sort of one host and the stable sort of another differ).  A query counts as a mismatch unless the chosen
+    neighbours have the same coordinates or, failing that, exactly the same fp32 distances (as the reference computes them) in
+    the same order."""
+    from oracle.tehnet_oracle import pairwise_sqdist          # the reference's own distance arithmetic (checker only)
+    B = query.shape[0]
+    bi = torch.arange(B).view(B, 1, 1)
+    same_pts = (known[bi, got] == known[bi, want]).all(-1)
+    d = pairwise_sqdist(query.float().contiguous(), known.float().contiguous())       # [B,N,S]
+    same_dist = torch.gather(d, 2, got) == torch.gather(d, 2, want)
+    return int((~(same_pts | same_dist)).any(-1).sum())
 
 
 def make_net(C, seed, device="cuda:0", precision="f32"):
@@ -68,11 +84,11 @@ def check_against(out, net, ref, trace, B, N):
     # sampled set holds duplicates, equal distances tie, and torch.sort's order among ties is unspecified
     l1_xyz = trace["l1_xyz"].permute(0, 2, 1)
     l2_xyz = trace["l2_xyz"].permute(0, 2, 1)
-    bi = torch.arange(B).view(B, 1, 1)
-    for tname, bname, shape, pts in (("fp2.nn_idx", "nn2_idx", (B, 512, 3), l2_xyz), ("fp1.nn_idx", "nn1_idx", (B, N, 3), l1_xyz)):
+    l0_xyz = net.net.debug_buffer("pts4").view(B, N, 4)[:, :, :3].cpu()
+    for tname, bname, shape, qry, pts in (("fp2.nn_idx", "nn2_idx", (B, 512, 3), l1_xyz, l2_xyz), ("fp1.nn_idx", "nn1_idx", (B, N, 3), l0_xyz, l1_xyz)):
         got = net.net.debug_buffer(bname, torch.int32).view(shape).cpu().long()
         want = torch.as_tensor(np.asarray(trace[tname])).long()
-        n = int((pts[bi, got] != pts[bi, want]).any(-1).sum())
+        n = nn_mismatches(qry, pts, got, want)
         if n:
             bad[tname] = n
     for tname, (bname, shape) in sel.items():
@@ -124,14 +140,47 @@ def test_forward_matches_reference_fixture(path, precision):
     _need_gpu()
     g = np.load(path)
     B, C, N, seed = [int(v) for v in g["meta"]]
-    net, sd, assets = make_net(C, seed, precision=precision)
+    mhlnes = bool(int(g["mhlnes"])) if "mhlnes" in g.files else False
+    os.environ["MHLNES"] = "1" if mhlnes else "0"          # read at construction, like TEHNet.py:148
+    try:
+        net, sd, assets = make_net(C, seed, precision=precision)
+    finally:
+        os.environ["MHLNES"] = "0"
+    assert net.net.mhlnes == int(mhlnes)
     xyz = torch.from_numpy(g["xyz"])
     inits = [torch.from_numpy(g["fps_init"][i].astype(np.int64)) for i in range(4)]
+    ties = "tie_eps" in g.files
+    if ties:         # near-tie segmentation head: the fixture was made with the checkpoint of oracle/stress.py
+        from oracle import mano_oracle, stress
+        hands = mano_oracle.make_hands(assets["left"], assets["right"])
+        net.load_state_dict(stress.near_tie_state_dict(sd, xyz, inits, hands, float(g["tie_eps"])), strict=True)
     net.net.fps_init = inits
+    xg = xyz.cuda()
     with torch.no_grad():
-        out = net(xyz.cuda())
+        out = net(xg)
     torch.cuda.synchronize()
-    assert np.array_equal(out["class_logits"].argmax(1).cpu().numpy(), g["argmax"])
+    if mhlnes:       # the reference overwrites channel 2 of the caller's tensor in place (TEHNet.py:176-177): so must the drop-in
+        assert np.array_equal(xg.cpu().numpy(), g["xyz_after"]) and not np.array_equal(g["xyz_after"], g["xyz"])
+    else:
+        assert torch.equal(xg.cpu(), xyz)
+    if ties:
+        # 5.6 % of the points have a top-2 margin below 1e-5 of the logit scale, 0.7 % below 1e-6.  Two correct fp32 evaluations of
+        # these 256-term sums differ by a few 1e-6 of the scale (tests/test_gpu_stress.py), so: every point whose margin in the
+        # reference is at least 2e-5 of the scale must get the reference's class; inside that band agreement is reported
+        lg = torch.from_numpy(g["class_logits"]).double()
+        top = lg.topk(2, dim=1).values
+        margin, scale = top[:, 0] - top[:, 1], float(lg.abs().max())
+        got = out["class_logits"].argmax(1).cpu()
+        want = torch.from_numpy(g["argmax"].astype(np.int64))
+        safe = margin >= 2e-5 * scale
+        inside = ~safe
+        print(f"near-ties [{precision}]: {int((margin < 1e-5 * scale).sum())} points < 1e-5 scale, {int(inside.sum())} inside the 2e-5 band, "
+              f"{int((got[inside] == want[inside]).sum())} of those agree; max |logit err| / scale = "
+              f"{float((out['class_logits'].cpu().double() - lg).abs().max()) / scale:.2e}")
+        assert float((margin < 1e-5 * scale).float().mean()) > 0.01
+        assert torch.equal(got[safe], want[safe])
+    else:
+        assert np.array_equal(out["class_logits"].argmax(1).cpu().numpy(), g["argmax"])
     assert rel(out["class_logits"], g["class_logits"]) < TOL
     for h, side in enumerate(("left", "right")):
         prm = torch.cat([out[side][k] for k in ("global_orient", "hand_pose", "betas", "transl")], 1)
@@ -143,14 +192,45 @@ def test_forward_matches_reference_fixture(path, precision):
         assert np.array_equal(got, g[name].astype(np.int32)), name
     # 3-NN by neighbour coordinates (ties among duplicated sample points have no defined order in torch.sort)
     l1_xyz = torch.from_numpy(g["sa1.new_xyz"]).permute(0, 2, 1)
-    bi = torch.arange(B).view(B, 1, 1)
     got = net.net.debug_buffer("nn1_idx", torch.int32).view(B, N, 3).cpu().long()
     want = torch.from_numpy(g["fp1.nn_idx"].astype(np.int64))
-    assert torch.equal(l1_xyz[bi, got], l1_xyz[bi, want])
+    l0_xyz = torch.from_numpy(g["xyz_after"] if mhlnes else g["xyz"])[:, :3].permute(0, 2, 1)
+    assert nn_mismatches(l0_xyz, l1_xyz, got, want) == 0
     assert rel(net.net.debug_buffer("nn1_w").view(B, N, 3), g["fp1.nn_w"]) < 1e-5
     hf = net.net.debug_buffer("hf8").view(2, B, N, 8)
     for h, side in enumerate(("left", "right")):
         assert rel(hf[h, :, :, :4].permute(0, 2, 1), g[side + ".hand_features"]) < TOL
+
+
+def test_foreign_mano_hands_are_called_like_the_reference_does():
+    """TEHNet.forward accepts ANY hand model with the adapter's interface (model/utils.py:14-31; TEHNet.py:92-105 only uses
+    .shapedirs.device, __call__ and .faces).  With such objects -- here the CPU oracle's hands -- the regressed parameters are
+    handed to them on their own device and their vertices / joints are returned, as the reference does."""
+    _need_gpu()
+    from oracle import mano_oracle
+    B, C, N, seed = 2, 4, 512, 21
+    net, sd, assets = make_net(C, seed)
+    xyz = synth.synth_cloud("E", B, C, N, seed)
+    inits = synth.fps_inits(B, N, seed)
+    foreign = mano_oracle.make_hands(assets["left"], assets["right"])          # CPU tensors, not ManoHand objects
+    with torch.no_grad():
+        net.net.fps_init = inits
+        native = net(xyz.cuda())
+        native = {s: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in native[s].items()} for s in ("left", "right")}
+        net.net.fps_init = inits
+        out = net.net(xyz.cuda(), foreign)
+        net.net.fps_init = inits
+        mixed = net.net(xyz.cuda(), {"left": net.hands["left"], "right": foreign["right"]})
+    for side in ("left", "right"):
+        assert out[side]["vertices"].device.type == "cpu" and out[side]["global_orient"].device.type == "cpu"
+        for k in ("global_orient", "hand_pose", "betas", "transl"):
+            assert torch.equal(out[side][k], native[side][k].cpu())
+        want = foreign[side](**{k: native[side][k].cpu() for k in ("global_orient", "hand_pose", "betas", "transl")})
+        assert torch.equal(out[side]["vertices"], want.vertices) and torch.equal(out[side]["j3d"], want.joints)
+        assert rel(out[side]["vertices"], native[side]["vertices"]) < 1e-5     # oracle MANO vs the HIP kernel
+        assert out[side]["faces"].shape == (B, 1538, 3)
+    assert mixed["left"]["vertices"].is_cuda and torch.equal(mixed["left"]["vertices"], native["left"]["vertices"])
+    assert torch.equal(mixed["right"]["vertices"], out["right"]["vertices"])
 
 
 def test_rng_draw_order_matches_reference():
@@ -228,6 +308,63 @@ def test_bf16_mode_reports_mpjpe_and_argmax_agreement():
     agree = float((outs["f32"]["logits"].argmax(1) == outs["bf16"]["logits"].argmax(1)).float().mean())
     print(f"bf16 vs fp32: root-relative MPJPE {mpjpe_mm:.4f} mm over 42 joints, argmax agreement {agree * 100:.3f} %")
     assert mpjpe_mm < 5.0 and agree > 0.97
+
+
+def test_bf16_mode_against_the_oracle():
+    """BASELINE.json config 3 against the CPU oracle (not only against the library's own fp32 mode): root-relative MPJPE in
+    mm (evaluate_ev2hands_r.py:43-54), segmentation argmax agreement, and exact selections of the first stage (selection math
+    stays fp32 in every mode; later selections depend on bf16-rounded features only through FPS/ball-query inputs, which are
+    coordinates -- so ALL selections must still be identical)."""
+    _need_gpu()
+    B, C, N, seed = 3, 4, 2048, 14
+    net, sd, assets = make_net(C, seed, precision="bf16")
+    xyz = synth.synth_cloud("E", B, C, N, seed)
+    inits = synth.fps_inits(B, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    torch.cuda.synchronize()
+    a = torch.cat([out["left"]["j3d"], out["right"]["j3d"]], 1).cpu()
+    b = torch.cat([ref["left"]["j3d"], ref["right"]["j3d"]], 1)
+    mpjpe_mm = float(((a - a[:, :1]) - (b - b[:, :1])).norm(dim=-1).mean() * 1000)
+    agree = float((out["class_logits"].argmax(1).cpu() == ref["class_logits"].argmax(1)).float().mean())
+    err = rel(out["class_logits"], ref["class_logits"])
+    print(f"bf16 vs oracle: root-relative MPJPE {mpjpe_mm:.4f} mm, argmax agreement {agree * 100:.3f} %, logits rel err {err:.2e}")
+    assert mpjpe_mm < 5.0 and agree > 0.97 and err < 5e-2
+    for tname, bname, shape in (("sa1.fps", "fps1", (B, 512)), ("sa2.fps", "fps2", (B, 128)), ("sa1.group2", "gidx1_2", (B, 512, 128)),
+                                ("sa2.group1", "gidx2_1", (B, 128, 128)), ("left_mano_regressor.sa1.group1", "gidxm1L", (B, 128, 128))):
+        got = net.net.debug_buffer(bname, torch.int32).view(shape).cpu().long()
+        assert torch.equal(got, torch.as_tensor(np.asarray(trace[tname])).long()), tname
+
+
+@pytest.mark.parametrize("precision,B,N", [("bf16", 256, 2048), ("f16x2", 128, 8192), ("bf16", 128, 8192), ("f32", 128, 8192)])
+def test_baseline_config_sizes_properties(precision, B, N):
+    """BASELINE.json config 3 (B=256, N=2048, bf16) and config 5 (N=8192 dense windows, B=128 per GPU) at full size, where the
+    CPU oracle would need minutes per window: size-independent properties -- all outputs finite, and reversing the order of the
+    windows (with their FPS inits) reverses every output bit-exactly; plus parity of window 0 run alone (B=1 is covered against
+    the oracle / the reference fixture at these N by test_forward_matches_oracle / ..._reference_fixture)."""
+    _need_gpu()
+    C, seed = 4, 15
+    net, sd, assets = make_net(C, seed, precision=precision)
+    xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    keys = (("class_logits", None), ("left", "vertices"), ("right", "j3d"), ("left", "betas"))
+    pick = lambda o: [o[a].clone() if b is None else o[a][b].clone() for a, b in keys]      # noqa: E731
+    with torch.no_grad():
+        net.net.fps_init = inits
+        fwd = pick(net(xyz))
+        net.net.fps_init = [t.flip(0) for t in inits]
+        rev = pick(net(xyz.flip(0).contiguous()))
+        net.net.fps_init = [t[:1] for t in inits]
+        one = pick(net(xyz[:1].contiguous()))
+    torch.cuda.synchronize()
+    for f, r, o in zip(fwd, rev, one):
+        assert torch.isfinite(f).all()
+        assert torch.equal(f.flip(0), r)
+        assert torch.equal(f[:1], o)
+    del net
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])

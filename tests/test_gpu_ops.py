@@ -300,3 +300,27 @@ def test_mano_layer(side):
     assert rel(got.vertices, ref.vertices) < 1e-5 and rel(got.joints, ref.joints) < 1e-5
     assert float((got.vertices.cpu().double() - ref64.vertices).abs().max()) < 1e-5     # metres
     assert float((got.joints.cpu().double() - ref64.joints).abs().max()) < 1e-5
+
+
+def test_mano_rotation_matrices_match_the_reference_formula():
+    """The rotation matrices ev2h_mano builds (exposed by ev2h_mano_rotations) against tests/golden/rodrigues_0.npz, which holds
+    outputs of the reference's own batch_rodrigues (/root/reference/src/Ev2Hands/losses.py:14-51, compiled from the reference
+    file by oracle/make_golden_rodrigues.py).  fp32 sin / cos / sqrt / divide of the device differ from the host's libm in the last
+    bits: 2e-6 absolute on matrix entries (entries are <= 1)."""
+    _need_gpu()
+    import os
+    from ev2hands_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rodrigues_0.npz"))
+    th, R = torch.from_numpy(g["theta"]), torch.from_numpy(g["R"])
+    M = th.shape[0]
+    pad = (-M) % 16
+    thp = torch.cat([th, torch.zeros(pad, 3)]).view(-1, 16, 3)
+    got = ops.mano_rotations(thp.cuda()).cpu().view(-1, 3, 3)[:M]
+    fin = torch.isfinite(R).all(-1).all(-1)
+    assert torch.equal(torch.isfinite(got).all(-1).all(-1), fin)            # theta + 1e-8 == 0: NaN in the reference, NaN here
+    err = float((got[fin] - R[fin]).abs().max())
+    print("rotation max abs err", err)
+    assert err < 2e-6
+    # tiny angles: where the 1e-8 offset decides the axis the matrices must still be rotations
+    eye_err = float((got[fin] @ got[fin].transpose(1, 2) - torch.eye(3)).abs().max())
+    assert eye_err < 2e-6

@@ -1,0 +1,153 @@
+"""GPU: range handling of the f16x2 arithmetic (include/ev2hands_hip.h "Range records").
+
+fp16 planes overflow at 65504 and go subnormal below 6e-5, so the two-plane split is only fp32-class when its operands sit in a
+good part of that range.  The library keeps a per-window maximum of every tensor a contraction reads and scales by exact powers of
+two; these tests drive it with checkpoints whose hidden activations are 1e-4 ... 1e+6 times the usual O(1) (the network function
+is unchanged: synth.rescale_hidden) and require the same parity bar as everywhere else -- 1e-4 relative on every output against
+the oracle, segmentation argmax and every FPS / ball-query / 3-NN selection identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ev2hands_amd import synth
+from test_gpu_forward import _need_gpu, check_against, rel, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(C, sd, seed, precision):
+    from ev2hands_amd.model import TEHNetWrapper
+    os.environ["ERPC"] = "1" if C == 5 else "0"
+    assets = {s: synth.synth_mano_assets(s, seed) for s in ("left", "right")}
+    net = TEHNetWrapper("cuda:0", mano_assets=assets, precision=precision)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    return net, assets
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "f32"])
+@pytest.mark.parametrize("alpha", [1e-4, 1e-3, 1e3, 6e4, 1e6])
+def test_hidden_activation_magnitude_does_not_matter(alpha, precision):
+    """Hidden activations alpha x O(1): 1e-4 and 1e-3 put unscaled low planes into the fp16 subnormals, 6e4 and 1e6 put unscaled
+    high planes at and beyond the fp16 maximum (65504)."""
+    _need_gpu()
+    C, N, B, seed = 4, 1024, 2, 11
+    sd = synth.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
+    net, assets = _net(C, sd, seed, precision)
+    xyz = synth.synth_cloud("E", B, C, N, seed)
+    inits = synth.fps_inits(B, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    assert 0.1 * alpha < float(trace["l0_points"].abs().max()) < 1e4 * alpha        # the hidden tensors really moved
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    torch.cuda.synchronize()
+    for k in ("class_logits",):
+        assert torch.isfinite(out[k]).all()
+    check_against(out, net, ref, trace, B, N)
+
+
+@pytest.mark.parametrize("alpha", [1e-4, 1.0, 1e6])
+def test_windows_of_one_batch_are_scaled_independently(alpha):
+    """A batch that mixes a normal window with one whose INPUT features are 1e4 times larger: every window must come out
+    exactly as when it is run alone (the scales are per window, so sharding a batch never changes a result)."""
+    _need_gpu()
+    C, N, seed = 5, 512, 12
+    sd = synth.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
+    net, assets = _net(C, sd, seed, "f16x2")
+    xyz = synth.synth_cloud("E", 3, C, N, seed)
+    xyz[1, 3:] *= 1e4                                   # event counts of window 1: far larger than its neighbours'
+    inits = synth.fps_inits(3, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    with torch.no_grad():
+        net.net.fps_init = inits
+        full = net(xyz.cuda())
+        torch.cuda.synchronize()
+        check_against(full, net, ref, trace, 3, N)           # (reads the debug buffers of THIS forward)
+        full = {"class_logits": full["class_logits"].clone(),
+                **{s_: {k: v.clone() for k, v in full[s_].items() if torch.is_tensor(v)} for s_ in ("left", "right")}}
+        outs = []
+        for b in range(3):
+            net.net.fps_init = [t[b:b + 1] for t in inits]
+            outs.append(net(xyz[b:b + 1].cuda()))
+    torch.cuda.synchronize()
+    for b in range(3):
+        assert torch.equal(full["class_logits"][b], outs[b]["class_logits"][0])
+        for side in ("left", "right"):
+            for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl"):
+                assert torch.equal(full[side][k][b], outs[b][side][k][0]), (b, side, k)
+
+
+def test_range_records_hold_the_exact_maxima():
+    """The records the consumers scale by are the exact per-window max |value| of the tensors in the workspace."""
+    _need_gpu()
+    C, N, B, seed = 4, 640, 3, 13
+    sd = synth.synth_state_dict(C, seed)
+    net, _ = _net(C, sd, seed, "f16x2")
+    xyz = synth.synth_cloud("U", B, C, N, seed)
+    net.net.fps_init = synth.fps_inits(B, N, seed)
+    with torch.no_grad():
+        net(xyz.cuda())
+    torch.cuda.synchronize()
+    dbg = net.net.debug_buffer
+    for rec, buf, shape, cols in (("l0", "l0", (B, N, 256), slice(0, 256)), ("l1a", "l1cat", (B, 512, 576), slice(0, 320)),
+                                  ("l1b", "l1cat", (B, 512, 576), slice(320, 576)), ("l2", "l2buf", (B, 128, 520), slice(0, 512)),
+                                  ("q1", "q1", (B, N, 512), slice(0, 512)), ("fp1in", "fp1in", (B, N, 128), slice(0, 128)),
+                                  ("l3", "l3", (B, 1, 1024), slice(0, 1024)), ("fc1L", "fc1L", (B, 1, 1024), slice(0, 1024)),
+                                  ("feat", "feat8", (B, N, 8), slice(0, 8)), ("hfR", "hf8", (2, B, N, 8), None)):
+        got = dbg("rng." + rec).view(torch.float32)[:B]
+        t = dbg(buf).view(shape)
+        want = t[1].abs().amax((1, 2)) if cols is None else t[:, :, cols].abs().amax((1, 2))
+        assert torch.equal(got, want), (rec, got, want)
+    # layer-1 tables are stored scaled: scale * (max |table| + |W1x|_1 r) stays below 2^15 and the record is the stored maximum
+    ps = dbg("p1scale").view(4, B)
+    for k, (rec, buf, shape) in enumerate((("p1a", "P1a", (B, N, 160)), ("p1b", "P1b", (B, 512, 256)), ("p1mL", "P1mL", (B, N, 256)),
+                                           ("p1mR", "P1mR", (B, N, 256)))):
+        got = dbg("rng." + rec).view(torch.float32)[:B]
+        want = dbg(buf).view(shape).abs().amax((1, 2))
+        assert torch.equal(got, want), rec
+        assert (got < 32768.0).all() and (ps[k] > 0).all()
+        assert torch.equal(torch.log2(ps[k]), torch.log2(ps[k]).round())        # powers of two
+
+
+@pytest.mark.parametrize("mag", [1e-6, 1e-3, 1.0, 3e4, 1e5, 1e9])
+@pytest.mark.parametrize("shape", [(384, 256, 192, 128), (256, 64, 128, 1), (300, 128, 24, 100)])
+def test_dense_f16x2_with_range_records(mag, shape):
+    """ev2h_gemm in F16X2 mode with X magnitudes from 1e-6 to 1e9 (far outside fp16) and per-group records: fp32-class result;
+    the output record equals the maximum of what was written."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    M, K, Nn, g = shape
+    gen = torch.Generator().manual_seed(5)
+    X = (torch.rand(M, K, generator=gen) * 2 - 1) * mag
+    ngrp = (M + g - 1) // g
+    scale = torch.logspace(-2, 0, ngrp).repeat_interleave(g)[:M, None]          # groups of different magnitude
+    X = (X * scale).contiguous()
+    W = (torch.rand(Nn, K, generator=gen) * 2 - 1) / K ** 0.5
+    b = torch.rand(Nn, generator=gen) * mag
+    want = (X.double() @ W.double().T + b.double()).clamp_min(0)
+    xa = ops.range_record(ngrp, "cuda")
+    Xp = torch.cat([X, torch.zeros(g * ngrp - M, K)]) if g * ngrp != M else X
+    xa.view(torch.float32).copy_(Xp.view(ngrp, g, K).abs().amax((1, 2)))
+    ya = ops.range_record(ngrp, "cuda")
+    Y = ops.dense(X.cuda(), W.cuda(), b.cuda(), relu=True, precision="f16x2", x_amax=xa, x_group_rows=g, y_amax=ya, y_group_rows=g)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    assert rel(Y, want) < 6e-6
+    Yp = torch.cat([Y.cpu(), torch.zeros(g * ngrp - M, Nn)]) if g * ngrp != M else Y.cpu()
+    assert torch.equal(ops.range_values(ya).cpu(), Yp.view(ngrp, g, Nn).abs().amax((1, 2)))
+
+
+def test_dense_f16x2_without_records_overflows_as_documented():
+    """The same call with NULL records splits X as it is: magnitudes beyond 65504 are outside the contract (inf / nan planes).
+    Kept as a test so that the behaviour the records exist to prevent stays visible."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    gen = torch.Generator().manual_seed(6)
+    X = (torch.rand(128, 64, generator=gen) * 2 - 1) * 1e6
+    W = (torch.rand(128, 64, generator=gen) * 2 - 1) / 8
+    Y = ops.dense(X.cuda(), W.cuda(), None, precision="f16x2")
+    torch.cuda.synchronize()
+    assert not torch.isfinite(Y).all()

@@ -35,7 +35,7 @@ def test_struct_layouts_and_abi_version(built):
     built.ev2h_struct_sizes(sizes)
     mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 2
+    assert built.ev2h_abi_version() == 3
 
 
 def test_workspace_size_grows_linearly(built):

@@ -25,6 +25,19 @@ def test_rodrigues_vs_scipy():
     assert np.abs(R0 - np.eye(3)).max() < 1e-6
 
 
+def test_rodrigues_is_pinned_to_the_reference_formula():
+    """tests/golden/rodrigues_0.npz holds outputs of the reference's own batch_rodrigues / quat_to_rotmat
+    (/root/reference/src/Ev2Hands/losses.py:14-51, compiled from the reference file by oracle/make_golden_rodrigues.py): the
+    oracle's rotation formula must reproduce them bit for bit, including the row where theta + 1e-8 vanishes (NaN)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rodrigues_0.npz"))
+    th, R = torch.from_numpy(g["theta"]), torch.from_numpy(g["R"])
+    mine = mano_oracle.rodrigues(th)
+    fin = torch.isfinite(R).all(-1).all(-1)
+    assert int((~fin).sum()) == 1 and torch.equal(torch.isfinite(mine).all(-1).all(-1), fin)
+    assert torch.equal(mine[fin], R[fin])
+
+
 @pytest.mark.parametrize("side", ["left", "right"])
 def test_rest_pose_is_template_plus_shape(side):
     a = assets(side, 3, zero_mean=True)

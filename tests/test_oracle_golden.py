@@ -11,7 +11,7 @@ import torch
 from ev2hands_amd import synth
 from oracle import mano_oracle, tehnet_oracle
 
-CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_")))
+CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_")))
 
 
 def rel(a, b):
@@ -31,14 +31,29 @@ def test_oracle_matches_reference_fixture(path):
     assert np.array_equal(torch.stack(inits).numpy(), g["fps_init"])
     sd = synth.synth_state_dict(C, seed)
     hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
+    if "tie_eps" in g.files:       # near-tie segmentation head (oracle/stress.py)
+        from oracle import stress
+        sd = stress.near_tie_state_dict(sd, xyz, inits, hands, float(g["tie_eps"]))
     trace = {}
+    mhlnes = bool(int(g["mhlnes"])) if "mhlnes" in g.files else False
+    xin = xyz.clone()
     with torch.no_grad():
-        out = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=trace)
+        out = tehnet_oracle.tehnet_forward(sd, xin, hands, fps_init=inits, trace=trace, mhlnes=mhlnes)
+    if mhlnes:       # TEHNet.py:176-177 overwrites channel 2 of the caller's tensor; the fixture holds what the reference left behind
+        assert np.array_equal(xin.numpy(), g["xyz_after"]) and not np.array_equal(xin.numpy(), g["xyz"])
+    else:
+        assert torch.equal(xin, xyz)
     # discrete selections: exact
     for k in g.files:
         if k.endswith(".fps") or ".group" in k or k.endswith(".nn_idx"):
             assert np.array_equal(trace[k].numpy(), g[k].astype(np.int64)), k
-    assert np.array_equal(out["class_logits"].argmax(1).numpy(), g["argmax"])
+    if "tie_eps" in g.files:       # points inside the float tolerance band may flip on another host's MKL path
+        lg = torch.from_numpy(g["class_logits"]).double()
+        top = lg.topk(2, dim=1).values
+        safe = (top[:, 0] - top[:, 1]) > 4e-6 * float(lg.abs().max())
+        assert np.array_equal(out["class_logits"].argmax(1).numpy()[safe.numpy()], g["argmax"][safe.numpy()])
+    else:
+        assert np.array_equal(out["class_logits"].argmax(1).numpy(), g["argmax"])
     # floats
     assert rel(out["class_logits"].numpy(), g["class_logits"]) < 2e-6
     for side in ("left", "right"):
