@@ -63,7 +63,10 @@ __device__ __forceinline__ void scale_rows(f32x4& v, float s) {
 // Epilogue shared by the three kernels.  acc[i][j][r] = output (row m0 + row0 + 32 i + mfma_row(r, half), column col0 + 32 j + l31):
 //   v = acc * (w_unscale / x_scale(row)) + bias;  ReLU;  post affine;  [* y_scale];  store, or max over the tile's 128 rows;
 //   optional atomicMax of |v| into the output's range record.
-template <int NS, int NI, int NJ>
+// GEN = false (the two fast kernels, and the generic one on aligned shapes): every 128-row tile lies inside one range group, so
+// the x scale, the storage scale and the output record are per tile.  GEN = true (generic kernel only; shapes whose groups
+// straddle tiles, e.g. N % 128 != 0, or one row per group: the per-window head layers): per row.
+template <int NS, int NI, int NJ, bool GEN>
 __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI][NJ], int m0, int row0, int col0, int wm, int wcol, int tile_cols,
                                               float* red, int tid) {
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -78,10 +81,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
         sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
         tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
     }
-    // x scale (and the table storage scale y_scale): one per tile when the tile lies inside one group, else one per row
     const bool xs_on = (NS == 2) && p.x_amax != nullptr;
     const bool ys_on = (NS == 2) && p.y_scale != nullptr;
-    const bool xs_uniform = !xs_on || (p.x_group_rows % GB_BM) == 0;
+    const bool track = (NS == 2) && p.y_amax != nullptr;
     auto y_store_scale = [&](long row) {          // power of two that keeps y_bound_w * max|X_g| + y_bound_b below 2^15
         const long rr = row < p.M ? row : p.M - 1;
         const long g = rr / p.x_group_rows;
@@ -91,21 +93,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
     };
     float cx_u = p.w_unscale;
     float sy_u = 1.f;
-    if (xs_on && xs_uniform) cx_u = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
-    if (ys_on && xs_uniform) sy_u = y_store_scale(m0);
+    if (xs_on) cx_u = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
+    if (ys_on) {
+        sy_u = y_store_scale(m0);
+        if (!GEN && tid == 0 && col0 == wcol && (m0 % p.y_group_rows) == 0) p.y_scale[m0 / p.y_group_rows] = sy_u;
+    }
     unsigned am = 0u;
-    const bool track = (NS == 2) && p.y_amax != nullptr;
-    const bool y_uniform = (p.y_group_rows % GB_BM) == 0;
+    float amf = 0.f;
     if (p.rowmax_rows == 0) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + row0 + i * 32 + mfma_row(r, half);
-                const float cx = xs_uniform ? cx_u : p.w_unscale * pow2_inverse(x_row_scale<NS>(p, row));
-                const float sy = (xs_uniform || !ys_on) ? sy_u : y_store_scale(row);
-                if (ys_on && row < p.M && (row % p.y_group_rows) == 0 && col0 + l31 == 0) p.y_scale[row / p.y_group_rows] = sy;
-                unsigned amr = 0u;
+                float cx = cx_u, sy = sy_u;
+                if constexpr (GEN) {
+                    if (xs_on) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, row));
+                    if (ys_on) {
+                        sy = y_store_scale(row);
+                        if (row < p.M && (row % p.y_group_rows) == 0 && col0 + l31 == 0) p.y_scale[row / p.y_group_rows] = sy;
+                    }
+                }
+                float amr = 0.f;           // |v| maxima as floats: one v_max_f32 with an abs modifier per value
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int col = col0 + j * 32 + l31;
@@ -115,20 +124,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
                     if constexpr (NS == 2) v *= sy;
                     if (row < p.M && col < p.N) {
                         p.Y[(long)row * p.ldy + col] = v;
-                        amr = max(amr, abs_bits(v));
+                        if constexpr (NS == 2) amr = fmaxf(amr, fabsf(v));
                     }
                 }
-                if (track) {
-                    if (y_uniform) am = max(am, amr);
-                    else {               // groups that straddle tiles, or one row per group: reduce over the 32 columns of the half-wave
+                if constexpr (GEN) {
+                    if (track) {           // reduce over the 32 columns of the half-wave, one atomic per row
+                        unsigned ab = __float_as_uint(amr);
 #pragma unroll
-                        for (int o = 16; o >= 1; o >>= 1) amr = max(amr, (unsigned)__shfl_xor((int)amr, o, 64));
-                        if (l31 == 0 && row < p.M && amr) atomicMax(&p.y_amax[row / p.y_group_rows], amr);
+                        for (int o = 16; o >= 1; o >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, o, 64));
+                        if (l31 == 0 && row < p.M && ab) atomicMax(&p.y_amax[row / p.y_group_rows], ab);
                     }
+                } else {
+                    amf = fmaxf(amf, amr);
                 }
             }
-        if (track && y_uniform) {
-            am = wave_max_u32_dpp(am);
+        if (!GEN && track) {
+            am = wave_max_u32_dpp(__float_as_uint(amf));
             if (lane == 0 && am) atomicMax(&p.y_amax[m0 / p.y_group_rows], am);
         }
     } else {
@@ -170,7 +181,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
     }
 }
 
-template <int NS>
+template <int NS, bool GEN>
 __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
     using Cfg = GBCfg<NS>;
     constexpr int RS = Cfg::RS;
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
     // loader: thread -> (row = tid / 4, 8 consecutive k = (tid % 4) * 8) of the A tile and of the B tile
     const int lrow = tid >> 2, lseg = tid & 3;
     f32x4 ra[2], rb[2];
-    const float xs = x_row_scale<NS>(p, m0 + lrow);
+    const float xs = x_row_scale<NS>(p, GEN ? m0 + lrow : m0);
 
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 8;
@@ -274,16 +285,16 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<NS, 2, 1>(p, acc, m0, wm * 64, n0 + wn * 32, wm, wn * 32, GB_BN, reinterpret_cast<float*>(smem), tid);
+    gemm_epilogue<NS, 2, 1, GEN>(p, acc, m0, wm * 64, n0 + wn * 32, wm, wn * 32, GB_BN, reinterpret_cast<float*>(smem), tid);
 }
 
-template <int NS>
+template <int NS, bool GEN>
 int launch_gb(const GemmBP& p, hipStream_t st) {
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<NS>),
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<NS, GEN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GBCfg<NS>::LDS_BYTES)););
-    gemm_nt_bf16_kernel<NS><<<p.nblk, GB_THREADS, GBCfg<NS>::LDS_BYTES, st>>>(p);
+    gemm_nt_bf16_kernel<NS, GEN><<<p.nblk, GB_THREADS, GBCfg<NS>::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
     const int nk = (p.K + GB_BK - 1) / GB_BK;
     f32x4 ra[2];             // X rows of the next K tile, in flight while the current tile is multiplied
     bool oka = true;         // zero fill is applied when the tile is written to LDS, not on the load
-    const float xs = x_row_scale<NS>(p, m0 + lrow);
+    const float xs = x_row_scale<NS>(p, m0);          // one range group per tile (ev2h_gemm_bf16 sends other shapes to the generic kernel)
 
     auto gload = [&](int kt) {
         const int k = kt * GB_BK + lseg * 8;
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         __builtin_amdgcn_s_barrier();
     }
 
-    gemm_epilogue<NS, 2, 2>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GW_BN, reinterpret_cast<float*>(smem), tid);
+    gemm_epilogue<NS, 2, 2, false>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GW_BN, reinterpret_cast<float*>(smem), tid);
 }
 
 template <int NS>
@@ -471,9 +482,10 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
     const int nk = (p.K + GB_BK - 1) / GB_BK;
     f32x4 ra[4], rh[4];
     bool oka = true, okh = true, fulla = true;      // fulla: all 16 floats of the segment lie inside the row (k + 16 <= K)
-    const float xs = x_row_scale<NS>(p, m0 + lrow);
-    // halo rows (TAP3, threads 0..3): rows m0 - 1 and m0 + 128 lie in the tile's window whenever they are used
-    const float xsh = TAP3 ? x_row_scale<NS>(p, (tid >> 1) ? (long)m0 + GB_BM : (long)m0 - 1) : 1.f;
+    // one range group per tile (ev2h_gemm_bf16 sends other shapes to the generic kernel); the TAP3 halo rows m0 - 1 and
+    // m0 + 128 lie in the tile's window whenever they are used, so they take the tile's scale too
+    const float xs = x_row_scale<NS>(p, m0);
+    const float xsh = xs;
 
     // 16 consecutive floats of one X row.  K is a multiple of 8, not of 16: when only the first 8 lie inside the row (`full`
     // false) the second half is read from the first half's address -- never past the row -- and zeroed when the tile is
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         }
     }
 
-    gemm_epilogue<NS, 2, 2>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
+    gemm_epilogue<NS, 2, 2, false>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
 }
 
 template <int NS, bool TAP3>
@@ -660,6 +672,15 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     }
     static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
     p.debug = dbg;
+    // range groups that do not tile by 128 rows (N % 128 != 0, or one row per group: the per-window head layers) take the
+    // generic kernel with the per-row epilogue; everything on the hot path is tile aligned
+    const bool general = (p.x_amax && p.x_group_rows % GB_BM != 0) ||
+                         (p.y_amax && d->rowmax_rows == 0 && p.y_group_rows % GB_BM != 0);
+    if (general) {
+        p.tiles_n = ceil_div(d->N, GB_BN);
+        p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
+        return launch_gb<2, true>(p, (hipStream_t)stream);
+    }
     if (d->Ws && d->ws_tile_rows == 128) {   // 128-row plane images: three small workgroups per CU
         p.tiles_n = ceil_div(d->N, GO_BN);
         p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
@@ -676,9 +697,9 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     }
     p.tiles_n = ceil_div(d->N, GB_BN);
     p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
-    if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3>(p, (hipStream_t)stream);
-    if (d->precision == EV2H_PREC_F16X2) return launch_gb<2>(p, (hipStream_t)stream);
-    if (d->precision == EV2H_PREC_BF16) return launch_gb<1>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3, false>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_F16X2) return launch_gb<2, false>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16) return launch_gb<1, false>(p, (hipStream_t)stream);
     ev2h_set_error("ev2h_gemm: unknown precision %d", d->precision);
     return EV2H_ERR_ARG;
 }

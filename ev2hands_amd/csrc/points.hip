@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
     if (!out) return;
     // each wave interpolates 64 of the block's points, lanes across channels (float4)
     const int D4 = D >> 2;
-    unsigned am = 0u;
+    float am = 0.f;                       // max |value| written by this lane (range record)
+#pragma unroll 1
     for (int t = wave * 64; t < wave * 64 + 64; ++t) {
         const int nn = blockIdx.x * NN_PTS_PER_WG + t;
         if (nn >= N1) break;
@@ -276,13 +277,12 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
             r.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(bq.z, w1)), __fmul_rn(cq.z, w2));
             r.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(bq.w, w1)), __fmul_rn(cq.w, w2));
             o[c] = r;
-            am = max(max(am, __float_as_uint(r.x) & 0x7fffffffu), max(__float_as_uint(r.y) & 0x7fffffffu,
-                     max(__float_as_uint(r.z) & 0x7fffffffu, __float_as_uint(r.w) & 0x7fffffffu)));
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
     }
     if (amax) {                          // range record of the interpolated rows (f16x2)
-        am = wave_max_u32_dpp(am);
-        if (lane == 0 && am) atomicMax(&amax[b], am);
+        const unsigned m = wave_max_u32_dpp(__float_as_uint(am));
+        if (lane == 0 && m) atomicMax(&amax[b], m);
     }
 }
 

@@ -157,6 +157,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             c2 = p.u2 * s2 * inv_s1;
             c3 = p.u3 * pow2_inverse(s2);
         }
+        // wave-uniform by construction (one group per wave): keep the three factors in scalar registers
+        s1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s1)));
+        c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c2)));
+        c3 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c3)));
     }
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
