@@ -11,6 +11,7 @@
 // in LDS with a (BK+4)-float row stride so the ds_read_b128 fragment reads are conflict free;
 // the next K tile is prefetched into registers while the current one is multiplied; two LDS
 // buffers -> one barrier per K tile.
+#include <cstdlib>
 #include "common.hpp"
 #include "ev2hands_hip.h"
 
@@ -176,7 +177,99 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmP p) {
     }
 }
 
-// tiny-N / odd-shape fallback is not needed: every layer of the path goes through the tile above.
+
+// ---------------------------------------------------------------------------------------- K = 8 layers
+// The layer-1 feature tables of the set abstractions that read the raw cloud (enc.sa1, both MANO regressors:
+// pointnet2_utils.py:248,253 with 4-5 feature channels padded to 8) are 8 -> 160 / 256 linear maps over B*N rows: 8 MACs per
+// 4-byte output, i.e. bound by writing the table (0.5 GB at B = 256).  A K = 32 MFMA tile wastes three quarters of the matrix
+// pipe on it and pays a 128-row tile prologue; here a lane owns four output columns (32 weights in registers), a wave walks
+// 32 consecutive rows whose 8 inputs arrive by scalar loads, and every row is one 1 KiB coalesced store.  Arithmetic: the fp32
+// fma chain in k order -- bit-identical to the f32 MFMA kernel -- in EVERY precision mode (the plane-split modes would only
+// approximate it).  F16X2 range handling as in gemm_bf16.hip (storage scale from a bound, output record).
+struct TableP {
+    const float* X; int ldx;
+    const float* W; int ldw;
+    float* Y; int ldy;
+    int M, N;
+    const float* bias;
+    int relu;
+    const unsigned* x_amax; const unsigned* x_amax2; int x_group_rows;
+    unsigned* y_amax; int y_group_rows;
+    float* y_scale; float y_bound_w, y_bound_b;
+};
+
+constexpr int TB_ROWS_PER_WAVE = 32, TB_WAVES = 4;
+
+__device__ __forceinline__ float tb_f16x2_scale(unsigned amax_bits) {      // planes.hpp: f16x2_scale
+    const int E = (int)((amax_bits >> 23) & 0xffu);
+    const int sb = (E == 255) ? 127 : min(268 - E, 200);
+    return __uint_as_float((unsigned)sb << 23);
+}
+
+__global__ __launch_bounds__(256) void table_k8_kernel(TableP p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long row_lo = ((long)blockIdx.x * TB_WAVES + wave) * TB_ROWS_PER_WAVE;
+    if (row_lo >= p.M) return;
+    const long row_hi = min((long)p.M, row_lo + TB_ROWS_PER_WAVE);
+    for (int cb = 0; cb < p.N; cb += 256) {
+        const int c0 = cb + 4 * lane;
+        const bool okc = c0 < p.N;                 // N % 4 == 0
+        float w[4][8], bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4* wr = reinterpret_cast<const float4*>(p.W + (long)(okc ? c0 + j : 0) * p.ldw);
+            const float4 a = wr[0], b = wr[1];
+            w[j][0] = a.x; w[j][1] = a.y; w[j][2] = a.z; w[j][3] = a.w; w[j][4] = b.x; w[j][5] = b.y; w[j][6] = b.z; w[j][7] = b.w;
+            bj[j] = (p.bias && okc) ? p.bias[c0 + j] : 0.f;
+        }
+        long next = row_lo;                        // first row of the next range group
+        long g = 0;
+        float sy = 1.f, am = 0.f;
+        auto flush = [&]() {                       // the finished group's maximum -> its record
+            if (p.y_amax) {
+                const unsigned m = wave_max_u32_dpp(__float_as_uint(am));
+                if (lane == 0 && m) atomicMax(&p.y_amax[g], m);
+            }
+            am = 0.f;
+        };
+        for (long row = row_lo; row < row_hi; ++row) {
+            if (row >= next && (p.y_scale || p.y_amax)) {      // wave-uniform
+                if (row > row_lo) flush();
+                const int gr = p.y_amax ? p.y_group_rows : p.x_group_rows;
+                g = row / gr;
+                next = (g + 1) * gr;
+                if (p.y_scale) {
+                    unsigned a = p.x_amax[g];
+                    if (p.x_amax2) a = max(a, p.x_amax2[g]);
+                    sy = tb_f16x2_scale(__float_as_uint(__fmaf_rn(p.y_bound_w, __uint_as_float(a), p.y_bound_b)));
+                    if (lane == 0 && cb == 0 && row == g * gr) p.y_scale[g] = sy;
+                }
+            }
+            const float4* xr = reinterpret_cast<const float4*>(p.X + row * p.ldx);       // wave-uniform address: scalar loads
+            const float4 xa = xr[0], xb = xr[1];
+            const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            float4 o;
+            float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = __fmaf_rn(x[k], w[j][k], acc);
+                float v = acc + bj[j];
+                if (p.relu) v = fmaxf(v, 0.f);
+                v *= sy;
+                ov[j] = v;
+                am = fmaxf(am, fabsf(v));
+            }
+            if (okc) *reinterpret_cast<float4*>(p.Y + row * p.ldy + c0) = o;
+            else am = 0.f;
+        }
+        if (p.y_amax) flush();
+    }
+}
+
+// tiny-N / odd-shape fallback is not needed: every other layer of the path goes through the tile above.
 
 // logits [B*N][4] point-major -> class_logits [B,4,N] (TEHNet.py:188 output layout)
 __global__ __launch_bounds__(256) void transpose_logits_kernel(const float4* __restrict__ pm, int N, float* __restrict__ cm) {
@@ -216,6 +309,25 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->post_scale == nullptr) == (d->post_shift == nullptr));
     p.rowmax_rows = d->rowmax_rows;
     if (d->rowmax_rows) EV2H_CHECK_ARG(d->rowmax_rows == BM && d->M % BM == 0);
+    static const bool no_table = getenv("EV2H_NO_TABLE_KERNEL") != nullptr;       // A/B switch
+    if (!no_table && d->K == 8 && d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->post_scale && (d->N % 4) == 0 &&
+        (d->ldy % 4) == 0 && (d->ldx % 4) == 0 && (d->ldw % 4) == 0) {      // (any M: a result must not depend on the batch size)
+        // write-bound K = 8 layer (the layer-1 tables of the raw cloud): exact fp32 fma chains in every precision mode
+        TableP t{};
+        t.X = d->X; t.ldx = d->ldx; t.W = d->W; t.ldw = d->ldw; t.Y = d->Y; t.ldy = d->ldy; t.M = d->M; t.N = d->N;
+        t.bias = d->bias; t.relu = d->relu;
+        if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+            t.x_amax = d->x_amax; t.x_amax2 = d->x_amax2; t.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
+            t.y_amax = d->y_amax; t.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
+            t.y_scale = d->y_scale; t.y_bound_w = d->y_bound_w; t.y_bound_b = d->y_bound_b;
+            if (t.y_scale) EV2H_CHECK_ARG(!t.y_amax || t.x_group_rows == t.y_group_rows);
+        } else if (d->precision == EV2H_PREC_F16X2 && d->y_amax) {
+            t.y_amax = d->y_amax; t.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
+        }
+        table_k8_kernel<<<ceil_div(d->M, TB_WAVES * TB_ROWS_PER_WAVE), 256, 0, (hipStream_t)stream>>>(t);
+        EV2H_CHECK_LAUNCH();
+        return EV2H_OK;
+    }
     if (d->precision != EV2H_PREC_F32) return ev2h_gemm_bf16(d, stream);
     const int tiles_m = ceil_div(d->M, BM);
     p.tiles_n = ceil_div(d->N, BN);
