@@ -127,7 +127,7 @@ class TEHNet(nn.Module):
         RNG (pointnet2_utils.py:75); same draws, same order: enc.sa1, enc.sa2, left.sa1, right.sa1."""
         return [torch.randint(0, hi, (B,), dtype=torch.long) for hi in (N, synth.SA1_NPOINT, N, N)]
 
-    def forward(self, xyz, mano_hands):
+    def _check_input(self, xyz):
         if self.training:
             raise NotImplementedError("ev2hands_amd implements the inference forward (net.eval()) only")
         if xyz.dim() != 3 or xyz.shape[1] != self.in_channels:
@@ -136,19 +136,15 @@ class TEHNet(nn.Module):
             raise RuntimeError("ev2hands_amd runs on the GPU only (there is no CPU fallback); move the input to cuda")
         if xyz.dtype != torch.float32:
             raise RuntimeError("input must be float32")
-        device = xyz.device
-        B, Cin, N = xyz.shape
-        L = _lib.lib()
-        if self.mhlnes:
-            if not xyz.is_contiguous():
-                raise RuntimeError("MHLNES=1 writes channel 2 in place and needs a contiguous input")
-            x = xyz
-        else:
-            x = xyz.contiguous()
-        inits = self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N)
-        self.fps_init = None
-        init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
+        if self.mhlnes and not xyz.is_contiguous():
+            raise RuntimeError("MHLNES=1 writes channel 2 in place and needs a contiguous input")
 
+    def _enqueue(self, x, init_dev, mano_hands):
+        """One ev2h_forward on the current stream: device work only (no host synchronisation, no host->device copy), so that it
+        can run under stream capture.  x [B,C,N] contiguous float32, init_dev [4,B] int64 on the device."""
+        device = x.device
+        B, Cin, N = x.shape
+        L = _lib.lib()
         pw = self.packed(device)
         # hand models from ev2hands_amd.create_mano_layers run inside ev2h_forward; any other object with the reference adapter's
         # interface (model/utils.py:14-31: .shapedirs, .faces, __call__(global_orient, hand_pose, betas, transl) -> .vertices,
@@ -185,10 +181,33 @@ class TEHNet(nn.Module):
                 d = {k: v.to(hd) for k, v in d.items()}
                 o = mano_hands[side](**d)
                 d = {"vertices": o.vertices, "j3d": o.joints, **d}
-            d["faces"] = np.tile(mano_hands[side].faces, (B, 1, 1))       # eval only (TEHNet.py:109-110)
             res[side] = d
         self._last_shape = (B, N)
         return res
+
+    def forward(self, xyz, mano_hands):
+        self._check_input(xyz)
+        device = xyz.device
+        B, Cin, N = xyz.shape
+        x = xyz if self.mhlnes else xyz.contiguous()
+        inits = self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N)
+        self.fps_init = None
+        init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
+        res = self._enqueue(x, init_dev, mano_hands)
+        for side in ("left", "right"):
+            res[side]["faces"] = np.tile(mano_hands[side].faces, (B, 1, 1))      # eval only (TEHNet.py:109-110)
+        return res
+
+    def capture(self, xyz, mano_hands, fps_init=None) -> "CapturedForward":
+        """Capture one forward for inputs of xyz's shape into a hipGraph (torch.cuda.CUDAGraph: stream capture of the kernel
+        sequence ev2h_forward enqueues, including its fork onto the library's side stream).  Replays cost one graph launch
+        instead of ~90 kernel launches -- what matters at the reference's operating point, one small batch at a time
+        (demo.py:24-33).  The returned object owns static input / FPS-init / output tensors; `replay(xyz, fps_init)` copies new
+        inputs in and returns the (static) output dict."""
+        self._check_input(xyz)
+        if not all(isinstance(mano_hands[s], ManoHand) for s in ("left", "right")):
+            raise TypeError("capture needs hand models from ev2hands_amd.create_mano_layers (foreign hand models run host code)")
+        return CapturedForward(self, xyz, mano_hands, fps_init)
 
     def debug_buffer(self, name: str, dtype=torch.float32) -> torch.Tensor:
         """Copy of a named workspace buffer of the last forward (parity tests)."""
@@ -200,6 +219,45 @@ class TEHNet(nn.Module):
             raise KeyError(name)
         off = p - self._ws.data_ptr()
         return self._ws[off:off + cnt.value * 4].view(dtype).clone()
+
+
+class CapturedForward:
+    """hipGraph of TEHNet.forward for one input shape (TEHNet.capture)."""
+
+    def __init__(self, net: TEHNet, xyz, mano_hands, fps_init=None):
+        device = xyz.device
+        B, _, N = xyz.shape
+        self.net, self.hands, self.B, self.N = net, mano_hands, B, N
+        self.x = xyz.detach().clone().contiguous()
+        inits = fps_init if fps_init is not None else net.draw_fps_init(B, N)
+        self.init = torch.stack([t.to(torch.long) for t in inits]).to(device).contiguous()
+        with torch.no_grad():
+            net._enqueue(self.x, self.init, mano_hands)      # warm-up outside the capture: per-kernel attributes, occupancy queries
+            torch.cuda.synchronize(device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = net._enqueue(self.x, self.init, mano_hands)
+        self.faces = {s: np.tile(mano_hands[s].faces, (B, 1, 1)) for s in ("left", "right")}
+        for s in ("left", "right"):
+            self.out[s]["faces"] = self.faces[s]
+        if net.mhlnes:
+            self.x.copy_(xyz)                                 # MHLNES=1 overwrote channel 2 during warm-up and capture
+
+    def replay(self, xyz=None, fps_init=None) -> dict:
+        """Run the captured forward (optionally on new inputs of the captured shape).  The returned tensors are the graph's static
+        outputs: they are overwritten by the next replay."""
+        if xyz is not None:
+            if tuple(xyz.shape) != tuple(self.x.shape):
+                raise RuntimeError(f"captured for input {tuple(self.x.shape)}, got {tuple(xyz.shape)}")
+            self.x.copy_(xyz, non_blocking=True)
+        if fps_init is not None:
+            self.init.copy_(torch.stack([t.to(torch.long) for t in fps_init]), non_blocking=True)
+        elif xyz is not None:
+            self.init.copy_(torch.stack(self.net.draw_fps_init(self.B, self.N)), non_blocking=True)     # reference RNG order
+        self.graph.replay()
+        if self.net.mhlnes and xyz is not None:
+            xyz[:, 2].copy_(self.x[:, 2])                     # the in-place overwrite of TEHNet.py:176-177 reaches the caller's tensor
+        return self.out
 
 
 # ------------------------------------------------------------------------------------ wrapper
@@ -253,3 +311,7 @@ class TEHNetWrapper:
 
     def __call__(self, inp):
         return self.net(inp, self.hands)
+
+    def capture(self, inp, fps_init=None):
+        """hipGraph of `self(inp)` for inputs of inp's shape: `g = net.capture(inp); out = g.replay(new_inp)` (TEHNet.capture)."""
+        return self.net.capture(inp, self.hands, fps_init)

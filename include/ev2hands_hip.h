@@ -205,17 +205,28 @@ int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, fl
  * and ncomps of `c` are used. */
 int ev2h_mano_rotations(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* rot, ev2h_stream_t stream);
 
-/* ---- event window -> [5, N] tensor (next row 8f-1; dataset/evaluation_stream.py:187-225, ev2hands_r.py:108-159) ---- */
-/* Per-pixel accumulation + np.nonzero-order compaction of B ragged windows.  events: device [E_total][4] float64 rows
- * (x, y, t_ms, polarity) in stream order, exactly the array the reference builds; offsets: device [B+1] row offsets
- * (<= 32768 events per window).  uniq [B][cap][8] float32 records (x, y, t_avg, pos_cnt, neg_cnt, 0, 0, 0) of the pixels
- * hit, in row-major pixel order; uniq_count [B] (-1 if a window is too large).  Bit-identical to np.add.at / np.nonzero. */
-int ev2h_event_window_build(const double* events, const int32_t* offsets, int B, int width, int height, int cap,
-                            int32_t* uniq_count, float* uniq, ev2h_stream_t stream);
-/* Resampling with replacement + pc_normalize: sample_idx [B][N] int32 (the reference draws them with
- * np.random.choice(M, N) on the host) -> out_cm [B][5][N] float32 = (x, y, t, pos_cnt, neg_cnt), the hot path's input. */
+/* ---- event window -> [5, N] tensor (next row 8f-1; dataset/evaluation_stream.py:187-225, ev2hands_r.py:108-159, erpc.py:169-249) ---- */
+/* Per-pixel accumulation + np.nonzero-order compaction of B ragged windows.  events: device float64 rows of ev_stride (>= 4)
+ * columns (x, y, t, polarity, ...) in stream order, exactly the arrays the reference builds; offsets: device [B+1] row offsets
+ * (<= 32768 events per window).  uniq [B][cap][8] float32 records (x, y, t_avg, pos_cnt, neg_cnt, 0, 0, 0) of the pixels hit, in
+ * row-major pixel order; uniq_count [B] (-1 if a window is too large).  Bit-identical to np.add.at / np.nonzero.
+ * raw_time = 0: evaluation builders (t minus the window's first timestamp, evaluation_stream.py:187);
+ * raw_time = 1: Ev2Hands-S builder (timestamps as they are, mean times 1e-6, erpc.py:178-191). */
+int ev2h_event_window_build(const double* events, int ev_stride, const int32_t* offsets, int B, int width, int height, int cap,
+                            int raw_time, int32_t* uniq_count, float* uniq, ev2h_stream_t stream);
+/* Ev2Hands-S only (erpc.py:207-211): unique pixels re-ordered by mean time (np.argsort; exactly equal times keep pixel order --
+ * numpy leaves their order undefined), first time subtracted.  uniq_out must differ from uniq_in; cap <= 16384.  labels_out
+ * [B][cap] (optional) = events[offsets[b] + perm[j]][label_col]: the per-event label column indexed with the per-pixel sort
+ * positions, as erpc.py:209 does. */
+int ev2h_event_window_timesort(const float* uniq_in, const int32_t* uniq_count, int cap, const double* events, int ev_stride,
+                               int label_col, const int32_t* offsets, int B, float* uniq_out, int32_t* labels_out,
+                               ev2h_stream_t stream);
+/* Resampling + pc_normalize: sample_idx [B][N] int32 (the reference draws them with np.random.choice on the host; for erpc.py's
+ * sampling=False branch pass arange(M) followed by the N - M drawn indices) -> out_cm [B][5][N] float32 = (x, y, t, pos_cnt,
+ * neg_cnt), the hot path's input.  uniq_labels [B][cap] / out_labels [B][N] int64 optional (Ev2Hands-S 'class_logits' target). */
 int ev2h_event_window_sample(const float* uniq, const int32_t* uniq_count, int cap, const int32_t* sample_idx, int B, int N,
-                             int width, int height, float* out_cm, ev2h_stream_t stream);
+                             int width, int height, float* out_cm, const int32_t* uniq_labels, int64_t* out_labels,
+                             ev2h_stream_t stream);
 
 /* ---- per-frame joint metrics (next row 8f-3; evaluate.py:185-234, evaluate_ev2hands_r.py:35-89) ------------------------ */
 /* j3d_left / j3d_right [B][21][3] float32 metres (the forward's outputs); j3d_gts [B][G][2][21][3] float64 metres (G ground-truth

@@ -81,3 +81,61 @@ def synth_event_stream(n: int, seed: int, width: int = OUTPUT_WIDTH, height: int
     y = np.clip(np.where(noise, uy, cy + g[:, 1]), 0, height - 1e-3)
     p = (hash_uniform(tag + "/p", (n,), seed) < 0.55)
     return np.stack([np.floor(x), np.floor(y), np.floor(t), p], 1).astype(np.int64)
+
+
+# ------------------------------------------------------------------------------------------------ Ev2Hands-S variant
+def build_window_s(rows: np.ndarray, sample_idx: np.ndarray | None = None, sampling: bool = True, n_events: int = 2048,
+                   width: int = OUTPUT_WIDTH, height: int = OUTPUT_HEIGHT):
+    """The synthetic-dataset builder, /root/reference/src/Ev2Hands/dataset/erpc.py:169-249 (Ev2HandSDataset.__getitem__,
+    augment off).  rows [n,6] float64 = (x, y, t, p, annotation_index, event_label) of n raw events.  Differences from the
+    evaluation builder above: timestamps are accumulated as they are and the per-pixel mean is multiplied by 1e-6 (:191);
+    the unique pixels are re-ordered by that mean time with np.argsort (:207) and the first one's time is subtracted (:211);
+    the per-EVENT labels are indexed with those per-PIXEL sort indices (:209, kept as it is); sampling=False keeps all pixels
+    and pads with resampled ones (:220-227).
+    Returns (events float32 [5, N'], labels int64 [N'], table float32 [M,5] in time order, time-ordered labels [M],
+    sample_idx) -- N' = n_events, or M when sampling is off and M == n_events.
+    np.argsort's default sort is not stable: among pixels with exactly equal mean time the reference's order depends on the
+    numpy build; this restatement (and the GPU kernel) take them in pixel order (stable)."""
+    x, y, t, p, _, lab = np.asarray(rows).T
+    grid = np.zeros((height, width, 3), dtype=np.float32)
+    cnt = np.zeros((height, width), dtype=np.float32)
+    x, y = x.astype(np.int32), y.astype(np.int32)
+    np.add.at(grid, (y, x, 0), t)
+    np.add.at(grid, (y, x, 1), p == 1)
+    np.add.at(grid, (y, x, 2), p != 1)
+    np.add.at(cnt, (y, x), 1)
+    yi, xi = np.nonzero(cnt)
+    t_avg = (grid[yi, xi, 0] / cnt[yi, xi]) * 1e-6
+    ev = np.hstack([xi[:, None], yi[:, None], t_avg[:, None], grid[yi, xi, 1][:, None], grid[yi, xi, 2][:, None]]).astype(np.float32)
+    lab = lab.astype(np.int32)
+    order = np.argsort(ev[:, 2], kind="stable")
+    ev = ev[order]
+    lab = lab[order]                       # erpc.py:209: per-event labels indexed by per-pixel sort positions, as the reference does
+    ev[:, 2] -= ev[0, 2]
+    table, table_lab = ev.copy(), lab.copy()
+    M = ev.shape[0]
+    if sampling:
+        if sample_idx is None:
+            sample_idx = np.random.choice(M, n_events)
+        ev, lab = ev[sample_idx], lab[sample_idx]
+    elif M < n_events:
+        if sample_idx is None:
+            sample_idx = np.random.choice(M, n_events - M)
+        ev, lab = np.concatenate([ev, ev[sample_idx]], 0), np.concatenate([lab, lab[sample_idx]], 0)
+    evt = torch.tensor(ev, dtype=torch.float32)
+    evt[:, :3] = normalize_points(evt[:, :3], width, height)
+    return evt.permute(1, 0).contiguous(), torch.tensor(lab, dtype=torch.long), table, table_lab, sample_idx
+
+
+def synth_s_rows(n: int, seed: int, start: int = 0) -> np.ndarray:
+    """n consecutive rows of a synthetic Ev2Hands-S event table: float64 (x, y, t_ns, p, annotation_index, label).
+    Timestamps are strictly increasing (1-3 us apart, nanosecond jitter) and counted from the start of the recording: unique raw times and small
+    magnitudes keep the float32 per-pixel mean times free of exact ties, whose order the reference leaves to np.argsort (real
+    tables have several events per microsecond and t ~ 1e9 ns, where such ties abound)."""
+    from ev2hands_amd.synth import hash_uniform
+    s = synth_event_stream(start + n, seed)
+    t_us = np.cumsum(1.0 + np.floor(hash_uniform(f"evS/{seed}/dt", (start + n,), seed) * 3.0))
+    t_ns = t_us * 1000.0 + np.floor(hash_uniform(f"evS/{seed}/ns", (start + n,), seed) * 1000.0)      # nanosecond jitter
+    lab = np.floor(hash_uniform(f"evS/{seed}/lab", (start + n,), seed) * 4)
+    rows = np.stack([s[:, 0], s[:, 1], t_ns, s[:, 3], np.zeros(start + n), lab], 1).astype(np.float64)
+    return rows[start:]

@@ -52,8 +52,8 @@ def bench_events(B=256, n_ev=2500):
     out = torch.empty(B, 5, 2048, device="cuda")
     L = _lib.lib()
     def fn():
-        _lib.check(L.ev2h_event_window_build(ev.data_ptr(), off.data_ptr(), B, 346, 260, bld.cap, counts.data_ptr(), table.data_ptr(), _lib.stream_handle()), "b")
-        _lib.check(L.ev2h_event_window_sample(table.data_ptr(), counts.data_ptr(), bld.cap, idt.data_ptr(), B, 2048, 346, 260, out.data_ptr(), _lib.stream_handle()), "s")
+        _lib.check(L.ev2h_event_window_build(ev.data_ptr(), 4, off.data_ptr(), B, 346, 260, bld.cap, 0, counts.data_ptr(), table.data_ptr(), _lib.stream_handle()), "b")
+        _lib.check(L.ev2h_event_window_sample(table.data_ptr(), counts.data_ptr(), bld.cap, idt.data_ptr(), B, 2048, 346, 260, out.data_ptr(), None, None, _lib.stream_handle()), "s")
     ms = timeit(fn, iters=10)
     t0 = time.time()
     for w, i in zip(wins[:32], idx[:32]):

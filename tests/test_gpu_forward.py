@@ -400,6 +400,40 @@ def test_full_size_batch_properties(precision):
         assert agree == 1.0
 
 
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+@pytest.mark.parametrize("B", [1, 8])
+def test_hipgraph_replay_is_bit_identical_to_eager(B, precision):
+    """ev2h_forward neither allocates nor synchronises, so the whole path (including the fork of the right-hand regressor onto the
+    library's side stream) can be captured into a hipGraph (TEHNet.capture).  Replays must reproduce the eager forward bit for
+    bit, on the captured inputs and on new inputs copied into the graph's static buffers."""
+    _need_gpu()
+    C, N, seed = 4, 2048, 17
+    net, sd, assets = make_net(C, seed, precision=precision)
+    xa = synth.synth_cloud("E", B, C, N, seed).cuda()
+    xb = synth.synth_cloud("U", B, C, N, seed + 1).cuda()
+    ia, ib = synth.fps_inits(B, N, seed), synth.fps_inits(B, N, seed + 1)
+
+    def flat(o):
+        return torch.cat([o["class_logits"].flatten()] + [o[s][k].flatten() for s in ("left", "right")
+                                                           for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl")]).clone()
+    with torch.no_grad():
+        net.net.fps_init = ia
+        ea = flat(net(xa))
+        net.net.fps_init = ib
+        eb = flat(net(xb))
+        g = net.capture(xa, fps_init=ia)
+        ga = flat(g.replay())
+        ga2 = flat(g.replay())
+        gb = flat(g.replay(xb, fps_init=ib))
+        ga3 = flat(g.replay(xa, fps_init=ia))
+        net.net.fps_init = ib
+        eb2 = flat(net(xb))                                   # eager still works after a capture
+    torch.cuda.synchronize()
+    assert torch.equal(ea, ga) and torch.equal(ea, ga2) and torch.equal(ea, ga3)
+    assert torch.equal(eb, gb) and torch.equal(eb, eb2)
+    assert g.out["left"]["faces"].shape == (B, 1538, 3)
+
+
 def test_two_stream_fork_is_bit_identical(tmp_path):
     """EV2H_TWO_STREAMS=1 (opt-in: right-hand regressor and the MANO ball queries on a second stream) must not change a bit.
     The switch is read once per process, so the forked run happens in a child process."""

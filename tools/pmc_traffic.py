@@ -22,13 +22,14 @@ def per_kernel(db, counter):
 
 
 fdb, wdb, prec, out = sys.argv[1:5]
+rnd = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
-res = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32-leg "
+res = {"command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-legs --no-latency --no-cpu-baseline "
                   f"--precision {prec} (second pass: --pmc WRITE_SIZE)",
        "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128 B request; KB units)",
-       "round": 1, "precision": prec, "kernels": {}}
+       "round": rnd, "precision": prec, "kernels": {}}
 for k in sorted(f, key=lambda k: -f[k][0]):
-    if k not in w or not (k.startswith("sa_mlp") or k.startswith("gemm_nt")):
+    if k not in w or not (k.startswith("sa_mlp") or k.startswith("gemm_nt") or k.startswith("table_k8")):
         continue
     fk, wk = f[k][0] / f[k][1], w[k][0] / w[k][1]
     res["kernels"][k] = {"launches": f[k][1], "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk,
