@@ -79,7 +79,7 @@ EXPORTS = [
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max",
     "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
-    "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions",
+    "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
 ]
 
 _lib = None
@@ -126,7 +126,8 @@ def lib() -> C.CDLL:
     L.ev2h_event_window_timesort.argtypes = [vp, vp, ci, vp, ci, ci, vp, ci, vp, vp, vp]
     L.ev2h_event_window_sample.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_joint_metrics.argtypes = [vp, vp, vp, ci, ci, ci, C.c_double, vp, vp, vp, vp, vp, vp]
-    L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, vp]
+    L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp]
+    L.ev2h_collision_penalty.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, C.c_double, vp, vp, ci, vp, vp]
     L.ev2h_profile_set.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), ci]
     sizes = (C.c_size_t * 6)()
     L.ev2h_struct_sizes(sizes)

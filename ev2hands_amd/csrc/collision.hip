@@ -27,6 +27,7 @@ struct ColP {
     int max_pairs;
     int32_t* pairs;                            // [B][max_pairs][2] or null
     int32_t* counts;                           // [B]
+    int cap;                                   // per-triangle cap on recorded pairs (the BVH's max_collisions), 0 = none
 };
 
 struct V3 { double x, y, z; };
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
                         V3 ta[3], tb[3];
                         tri(fi, ta);
                         tri(fj, tb);
-                        if (sat_intersect(ta, tb)) {
+                        if ((p.cap <= 0 || cnt < p.cap) && sat_intersect(ta, tb)) {      // at most `cap` pairs per triangle i, in j order
                             if (pass && out && base + cnt < p.max_pairs) { out[2 * (base + cnt)] = i; out[2 * (base + cnt) + 1] = j; }
                             ++cnt;
                         }
@@ -157,14 +158,96 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------- penetration penalty
+// Conic distance-field penalty of the colliding pairs (losses.py:60-102: CollisionLoss -> torch-mesh-isect's
+// DistanceFieldPenetrationLoss(sigma = 0.5, point2plane = False, penalize_outside = False); un-vendored, restated from the
+// published definition, Tzionas et al., IJCV 2016, eq. 11-14 -- parity unpinned, oracle/collision_oracle.py).  For a triangle f
+// with circumcentre o, circumradius r and unit normal n, a point v at depth h = -n.(v - o) >= 0 behind the face lies in a cone
+// whose radius grows as r (1 + h / sigma);  Phi = |(v - o) + h n| / (r (1 + h / sigma));  Psi = (1 - Phi)^2 if Phi < 1 (and the
+// point is not in front of the face), else 0;  a pair (i, j) costs  sum_{v in j} Psi_i(v)^2 + sum_{v in i} Psi_j(v)^2.
+struct PenP {
+    const float* vl; const float* vr; const int32_t* fl; const int32_t* fr;
+    int nv, nf; float scale; double sigma;
+    const int32_t* pairs; const int32_t* counts; int max_pairs;
+    double* loss;
+};
+
+__device__ double cone_term(const V3 (&f)[3], const V3 (&q)[3], double sigma) {
+    const V3 a = sub(f[1], f[0]), b = sub(f[2], f[0]);
+    const V3 axb = cross(a, b);
+    const double n2 = dot(axb, axb);
+    if (n2 < 1e-300) return 0.0;                                 // degenerate face: no cone
+    // circumcentre o = f0 + ((|a|^2 b - |b|^2 a) x (a x b)) / (2 |a x b|^2);  circumradius r = |a| |b| |a - b| / (2 |a x b|)
+    const double a2 = dot(a, a), b2 = dot(b, b);
+    const V3 t = {a2 * b.x - b2 * a.x, a2 * b.y - b2 * a.y, a2 * b.z - b2 * a.z};
+    const V3 c = cross(t, axb);
+    const V3 o = {f[0].x + c.x / (2 * n2), f[0].y + c.y / (2 * n2), f[0].z + c.z / (2 * n2)};
+    const V3 amb = sub(a, b);
+    const double r = sqrt(a2) * sqrt(b2) * sqrt(dot(amb, amb)) / (2 * sqrt(n2));
+    const double inv = 1.0 / sqrt(n2);
+    const V3 n = {axb.x * inv, axb.y * inv, axb.z * inv};
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const V3 d = sub(q[k], o);
+        const double along = dot(d, n);                         // > 0: in front of the face (penalize_outside = False: free)
+        if (along > 0.0) continue;
+        const V3 rad = {d.x - along * n.x, d.y - along * n.y, d.z - along * n.z};
+        const double phi = sqrt(dot(rad, rad)) / (r * (1.0 - along / sigma));
+        if (phi < 1.0) { const double psi = (1.0 - phi) * (1.0 - phi); s += psi * psi; }
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void collision_penalty_kernel(PenP p) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(p.counts[b], p.max_pairs);
+    const int32_t* pr = p.pairs + (size_t)b * p.max_pairs * 2;
+    auto vert = [&](int v) -> V3 {
+        const float* src = v < p.nv ? p.vl + ((size_t)b * p.nv + v) * 3 : p.vr + ((size_t)b * p.nv + (v - p.nv)) * 3;
+        return {(double)__fmul_rn(src[0], p.scale), (double)__fmul_rn(src[1], p.scale), (double)__fmul_rn(src[2], p.scale)};
+    };
+    auto tri = [&](int f, V3 (&t)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = vert(f < p.nf ? p.fl[f * 3 + k] : p.fr[(f - p.nf) * 3 + k] + p.nv);
+    };
+    double s = 0.0;
+    for (int q = tid; q < n; q += 256) {
+        V3 ti[3], tj[3];
+        tri(pr[2 * q], ti);
+        tri(pr[2 * q + 1], tj);
+        s += cone_term(ti, tj, p.sigma) + cone_term(tj, ti, p.sigma);
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {                          // fixed tree: deterministic
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) p.loss[b] = red[0];
+}
+
 }  // namespace
+
+extern "C" int ev2h_collision_penalty(const float* verts_left, const float* verts_right, const int32_t* faces_left,
+                                      const int32_t* faces_right, int B, int nv, int nf, float scale, double sigma, const int32_t* pairs,
+                                      const int32_t* counts, int max_pairs, double* loss, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(verts_left && verts_right && faces_left && faces_right && pairs && counts && loss);
+    EV2H_CHECK_ARG(B > 0 && nv >= 3 && nf >= 1 && max_pairs > 0 && sigma > 0.0);
+    PenP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, sigma, pairs, counts, max_pairs, loss};
+    collision_penalty_kernel<<<B, 256, 0, (hipStream_t)stream>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
 
 extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left,
                                     const int32_t* faces_right, int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs,
-                                    int32_t* counts, ev2h_stream_t stream) {
+                                    int32_t* counts, int max_per_triangle, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(verts_left && verts_right && faces_left && faces_right && counts);
     EV2H_CHECK_ARG(B > 0 && nv >= 3 && nv <= COL_MAX_V && nf >= 1 && nf <= COL_MAX_F && max_pairs >= 0 && (pairs || max_pairs == 0));
-    ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts};
+    EV2H_CHECK_ARG(max_per_triangle >= 0);
+    ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts, max_per_triangle};
     const size_t lds = (size_t)(3 * 2 * nv) * 4 + (size_t)(3 * 2 * nf) * 4 + (size_t)(6 * 2 * nf) * 4 + (size_t)(2 * nf + 1) * 4 +
                        COL_THREADS * 4;
     static PerDevice attr_set{};

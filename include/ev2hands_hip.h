@@ -245,7 +245,20 @@ int ev2h_joint_metrics(const float* j3d_left, const float* j3d_right, const doub
  * lexicographic (i < j) order.  The reference obtains its pairs from the un-vendored torch-mesh-isect BVH with a
  * per-triangle candidate cap; this is the uncapped quantity (parity unpinned, oracle/collision_oracle.py). */
 int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left, const int32_t* faces_right,
-                         int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs, int32_t* counts, ev2h_stream_t stream);
+                         int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs, int32_t* counts, int max_per_triangle,
+                         ev2h_stream_t stream);
+/* max_per_triangle > 0: at most that many pairs (i, j > i) are counted and listed per triangle i, the first ones in j order -- the
+ * role of the reference BVH's `max_collisions` (8 in evaluate_ev2hands_r.py:131, 16 in losses.py:62).  Which pairs the reference's
+ * tree keeps beyond its cap depends on its traversal order (not reproducible); the two agree whenever no triangle exceeds the cap. */
+
+/* Penetration penalty of the listed pairs (losses.py:60-102 CollisionLoss: torch-mesh-isect DistanceFieldPenetrationLoss with
+ * sigma = 0.5, point2plane = False, penalize_outside = False; restated from Tzionas et al. IJCV 2016 eq. 11-14, parity unpinned).
+ * pairs / counts / max_pairs as written by ev2h_mesh_collisions for the same meshes and scale (1.0: the loss works in metres).
+ * loss [B] float64 = sum over the window's pairs of both triangles' conic distance-field terms; the caller applies the
+ * reference's reduction (mean over the windows with a non-zero loss, times collision_weight = 100). */
+int ev2h_collision_penalty(const float* verts_left, const float* verts_right, const int32_t* faces_left, const int32_t* faces_right,
+                           int B, int nv, int nf, float scale, double sigma, const int32_t* pairs, const int32_t* counts, int max_pairs,
+                           double* loss, ev2h_stream_t stream);
 
 /* ---- whole path -------------------------------------------------------------------------------------- */
 typedef struct ev2h_sa_branch {

@@ -58,8 +58,10 @@ def sat_intersect(a, b):
     return ~sep
 
 
-def collision_pairs(vertices, faces):
-    """All unordered pairs (i < j, lexicographic order) of triangles without a common vertex index that intersect."""
+def collision_pairs(vertices, faces, max_per_triangle: int = 0):
+    """All unordered pairs (i < j, lexicographic order) of triangles without a common vertex index that intersect.
+    max_per_triangle > 0 keeps at most that many pairs per triangle i (the first ones in j order): the role of the reference
+    BVH's `max_collisions` cap (which pairs ITS traversal keeps beyond the cap is not reproducible: parity unpinned)."""
     tri = vertices[faces]                                     # [F,3,3]
     lo, hi = tri.min(1), tri.max(1)
     F = faces.shape[0]
@@ -75,15 +77,62 @@ def collision_pairs(vertices, faces):
         if j.size == 0:
             continue
         hit = sat_intersect(np.broadcast_to(tri[i], (j.size, 3, 3)), tri[j])
-        out += [(i, int(k)) for k in j[hit]]
+        js = j[hit]
+        if max_per_triangle > 0:
+            js = js[:max_per_triangle]
+        out += [(i, int(k)) for k in js]
     return np.asarray(out, dtype=np.int64).reshape(-1, 2)
 
 
-def non_collision_score(verts_left, verts_right, faces_left, faces_right):
-    """evaluate_ev2hands_r.py:149-157 with the pair count defined above."""
+def non_collision_score(verts_left, verts_right, faces_left, faces_right, max_collisions: int = 0):
+    """evaluate_ev2hands_r.py:149-157 with the pair count defined above (max_collisions: the BVH cap, 8 there)."""
     v, f = build_triangles(verts_left, verts_right, faces_left, faces_right)
-    n = collision_pairs(v, f).shape[0]
+    n = collision_pairs(v, f, max_collisions).shape[0]
     return 100 - round(n / f.shape[0] * 100, 2), n
+
+
+# ---- penetration penalty of the training loss (losses.py:60-102)
+def cone_term(face, pts, sigma: float = 0.5):
+    """Conic distance-field term of one triangle `face` [3,3] for the points `pts` [n,3] (float64): Tzionas et al., IJCV 2016,
+    eq. 11-14, the definition torch-mesh-isect's DistanceFieldPenetrationLoss implements (sigma = 0.5, point2plane = False,
+    penalize_outside = False at the reference's call site, losses.py:70-72; the package is not vendored: PARITY UNPINNED).
+    o, r = circumcentre / circumradius of the face, n its unit normal; a point at depth h = -n.(p - o) >= 0 behind the face is
+    inside the cone when Phi = |radial offset| / (r (1 + h / sigma)) < 1 and then costs Psi^2 with Psi = (1 - Phi)^2; points in
+    front of the face (h < 0) or outside the cone cost nothing.  Returns the sum over the points."""
+    f = np.asarray(face, dtype=np.float64)
+    a, b = f[1] - f[0], f[2] - f[0]
+    axb = np.cross(a, b)
+    n2 = axb @ axb
+    if n2 < 1e-300:
+        return 0.0
+    o = f[0] + np.cross((a @ a) * b - (b @ b) * a, axb) / (2 * n2)
+    r = np.linalg.norm(a) * np.linalg.norm(b) * np.linalg.norm(a - b) / (2 * np.sqrt(n2))
+    n = axb / np.sqrt(n2)
+    d = np.asarray(pts, dtype=np.float64) - o
+    along = d @ n
+    rad = np.linalg.norm(d - along[:, None] * n, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):      # the cone's apex (along = sigma) lies in front of the face: masked below
+        phi = rad / (r * (1.0 - along / sigma))
+    psi = np.where((along <= 0) & (phi < 1), (1 - phi) ** 2, 0.0)
+    return float((psi ** 2).sum())
+
+
+def penetration_loss(vertices, faces, pairs, sigma: float = 0.5):
+    """Sum over the colliding pairs of both triangles' cone terms evaluated at the other triangle's vertices (one window)."""
+    tri = np.asarray(vertices, dtype=np.float64)[faces]
+    return float(sum(cone_term(tri[i], tri[j], sigma) + cone_term(tri[j], tri[i], sigma) for i, j in pairs))
+
+
+def collision_loss(verts_left, verts_right, faces_left, faces_right, max_collisions: int = 16, sigma: float = 0.5, weight: float = 1e2):
+    """CollisionLoss.__call__ (losses.py:77-102) for a batch: verts_* [B,778,3] float32 METRES (the loss does not rescale).
+    Returns (loss value, per-window penalties)."""
+    per = []
+    for vl, vr in zip(verts_left, verts_right):
+        v, f = build_triangles(vl, vr, faces_left, faces_right, scale=1.0)
+        per.append(penetration_loss(v, f, collision_pairs(v, f, max_collisions), sigma))
+    per = np.asarray(per)
+    nz = per[per != 0]
+    return (float(nz.mean() * weight) if nz.size else 0.0), per
 
 
 # ---- independent check used by the tests: two triangles in general position intersect iff an edge of one pierces the other

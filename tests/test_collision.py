@@ -75,8 +75,10 @@ def test_gpu_pairs_match_oracle(level):
         ref = CO.collision_pairs(verts, faces)
         assert counts[b] == ref.shape[0], (b, counts[b], ref.shape[0])
         assert np.array_equal(pairs[b, :counts[b]], ref)
-    scores, _ = compute_non_collision_score(torch.from_numpy(vl).cuda(), f, torch.from_numpy(vr).cuda(), f)
+    scores, _ = compute_non_collision_score(torch.from_numpy(vl).cuda(), f, torch.from_numpy(vr).cuda(), f, max_collisions=0)
     assert scores == [CO.non_collision_score(vl[b], vr[b], f, f)[0] for b in range(B)]
+    scores8, _ = compute_non_collision_score(torch.from_numpy(vl).cuda(), f, torch.from_numpy(vr).cuda(), f)       # the reference's cap of 8
+    assert scores8 == [CO.non_collision_score(vl[b], vr[b], f, f, 8)[0] for b in range(B)]
     assert counts[0] == 0 and counts[1] > 0
 
 
@@ -102,3 +104,62 @@ def test_gpu_mano_sized_meshes_and_truncation():
         ref = CO.collision_pairs(verts, faces)
         assert counts[b] == ref.shape[0] and counts[b] > 1000
         assert np.array_equal(pairs[b], ref[:1000])
+
+
+def test_cone_term_known_answers():
+    """Conic distance field (Tzionas et al. eq. 11-14): a right triangle with legs 2 has circumcentre (1, 1, 0) and
+    circumradius sqrt(2)."""
+    f = np.array([[0, 0, 0], [2, 0, 0], [0, 2, 0]], dtype=np.float64)           # normal +z
+    sig = 0.5
+    assert CO.cone_term(f, np.array([[1.0, 1.0, 0.0]]), sig) == pytest.approx(1.0)                 # on the axis, on the face: Psi = 1
+    assert CO.cone_term(f, np.array([[1.0, 1.0, 0.5]]), sig) == 0.0                                # in front of the face: free
+    assert CO.cone_term(f, np.array([[1.0 + np.sqrt(2), 1.0, 0.0]]), sig) == pytest.approx(0.0)    # on the circumcircle: Phi = 1
+    # depth h = 0.5 = sigma doubles the cone radius: a point at radial distance sqrt(2) has Phi = 1/2, Psi = 1/4, cost 1/16
+    assert CO.cone_term(f, np.array([[1.0 + np.sqrt(2), 1.0, -0.5]]), sig) == pytest.approx(1.0 / 16)
+    # rigid motion invariance and additivity over points
+    rng = np.random.default_rng(3)
+    pts = rng.normal(size=(5, 3)) * 0.5 + np.array([1, 1, -0.3])
+    R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    R *= np.sign(np.linalg.det(R))
+    t = rng.normal(size=3)
+    assert CO.cone_term(f @ R.T + t, pts @ R.T + t, sig) == pytest.approx(CO.cone_term(f, pts, sig), rel=1e-12)
+    assert CO.cone_term(f, pts, sig) == pytest.approx(sum(CO.cone_term(f, p[None], sig) for p in pts), rel=1e-12)
+
+
+def test_collision_loss_reduction_matches_the_call_site():
+    """losses.py:96-100: mean over the windows with a non-zero penalty, times 100; 0 when nothing collides."""
+    v, f = CO.icosphere(2)
+    vl = np.stack([(v * 0.040).astype(np.float32)] * 3)
+    vr = np.stack([(v * 0.040 + np.array(o)).astype(np.float32) for o in ([0.2, 0, 0], [0.05, 0.003, 0.001], [0.03, 0.02, -0.01])])
+    loss, per = CO.collision_loss(vl, vr, f, f)
+    assert per[0] == 0 and per[1] > 0 and per[2] > 0
+    assert loss == pytest.approx(per[1:].mean() * 100)
+    assert CO.collision_loss(vl[:1], vr[:1], f, f)[0] == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_collision_loss_matches_oracle():
+    """ev2h_mesh_collisions (scale 1, cap 16) + ev2h_collision_penalty + the call site's reduction against the float64 oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ev2hands_amd.collision import CollisionLoss, mesh_collisions
+    v, f = CO.icosphere(3)
+    rng = np.random.default_rng(7)
+    B = 5
+    vl = np.stack([(v * 0.040 * (1 + 0.05 * rng.normal(size=(1, 3)))).astype(np.float32) for _ in range(B)])
+    off = np.array([[0.2, 0, 0], [0.05, 0.003, 0.001], [0.03, 0.02, -0.01], [0.0795, 0.001, 0.002], [0.01, 0.0, 0.0]])
+    vr = np.stack([(v * 0.040 + off[b]).astype(np.float32) for b in range(B)])
+    outs = {"left": {"vertices": torch.from_numpy(vl).cuda(), "faces": f}, "right": {"vertices": torch.from_numpy(vr).cuda(), "faces": f}}
+    cl = CollisionLoss("cuda:0")
+    per = cl.per_window(outs).cpu().numpy()
+    want, want_per = CO.collision_loss(vl, vr, f, f)
+    assert want_per[0] == 0 and (want_per[1:3] > 0).all()
+    assert np.allclose(per, want_per, rtol=1e-9, atol=1e-300)
+    assert float(cl(outs)) == pytest.approx(want, rel=1e-6)
+    # the cap of 16 pairs per triangle is active for the deeply interpenetrating window
+    c16, _ = mesh_collisions(outs["left"]["vertices"], outs["right"]["vertices"], f, f, scale=1.0, max_per_triangle=16)
+    c0, _ = mesh_collisions(outs["left"]["vertices"], outs["right"]["vertices"], f, f, scale=1.0)
+    assert (c16 <= c0).all() and int(c16[4]) <= int(c0[4])
+    for b in (1, 4):
+        vv, ff = CO.build_triangles(vl[b], vr[b], f, f, scale=1.0)
+        assert int(c16[b]) == CO.collision_pairs(vv, ff, 16).shape[0]

@@ -67,5 +67,5 @@ def test_events_to_scores_end_to_end():
         assert abs(scores[b]["joint_loss"] - want["joint_loss"]) < 1e-3 * max(1.0, abs(want["joint_loss"]))
         # the collision count is discrete: compare on the GPU's own vertices
         sc, _n = collision_oracle.non_collision_score(out["left"]["vertices"][b].cpu().numpy(), out["right"]["vertices"][b].cpu().numpy(),
-                                                      np.asarray(net.hands["left"].faces), np.asarray(net.hands["right"].faces))
-        assert ncs[b] == sc
+                                                      np.asarray(net.hands["left"].faces), np.asarray(net.hands["right"].faces), 8)
+        assert ncs[b] == sc                                   # (max_collisions = 8 per triangle, evaluate_ev2hands_r.py:131)
