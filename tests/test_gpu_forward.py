@@ -278,6 +278,22 @@ def test_state_dict_roundtrip_and_module_prefix():
         net.load_state_dict(bad, strict=True)
 
 
+def test_window_size_limits_match_the_reference_domain():
+    """N < 128 is outside the reference's own domain: query_ball_point takes `[:, :, :nsample]` of an N-column tensor and then
+    indexes it with an nsample-column mask (pointnet2_utils.py:103-106), an IndexError as soon as N < 128 = the largest nsample
+    (checked here on the oracle, which restates those lines).  The library rejects such windows with an error instead."""
+    _need_gpu()
+    from ev2hands_amd import _lib
+    net, sd, assets = make_net(4, 0)
+    xyz = synth.synth_cloud("U", 1, 4, 64, 0)
+    with pytest.raises(IndexError):
+        run_oracle(sd, assets, xyz, synth.fps_inits(1, 64, 0))
+    with pytest.raises(_lib.Ev2hError, match="bad argument"):
+        net(xyz.cuda())
+    with pytest.raises(_lib.Ev2hError, match="bad argument"):
+        net(torch.zeros(1, 4, 8320, device="cuda"))              # > 8192: the documented upper limit of the selection kernels
+
+
 def test_training_forward_is_refused():
     _need_gpu()
     net, sd, assets = make_net(4, 0)
