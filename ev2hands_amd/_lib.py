@@ -43,7 +43,7 @@ class SaBranch(C.Structure):
 
 class SaModule(C.Structure):
     _fields_ = [("W1f", vp), ("b1", vp), ("kf", ci), ("npoint", ci), ("nbranch", ci), ("br", SaBranch * 3),
-                ("w1f_unscale", C.c_float), ("w1f_norm", C.c_float), ("b1_max", C.c_float)]
+                ("w1f_unscale", C.c_float), ("W1fs", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float)]
 
 
 class Dense(C.Structure):

@@ -286,6 +286,7 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
     g.M = B * Npts; g.N = c1sum; g.K = m.kf; g.bias = m.b1; g.taps = 1;
     g.precision = precision;
     g.w_unscale = m.w1f_unscale;
+    if (precision != EV2H_PREC_F32 && m.W1fs) { g.Ws = m.W1fs; g.ws_tile_rows = 128; }
     if (feat_amax) {
         g.x_amax = feat_amax; g.x_group_rows = Npts;
         g.y_amax = p1_amax; g.y_group_rows = Npts;

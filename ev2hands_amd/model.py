@@ -93,9 +93,10 @@ class TEHNet(nn.Module):
         self.left_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.right_mano_regressor = _RegressorParams(n_pose_params=n_pose_params)
         self.mhlnes = int(os.getenv("MHLNES", 0))
-        # arithmetic of the matrix contractions: "f32" (exact fp32 MFMA, default here), "f16x2" / "bf16x3"
-        # (fp32-class split arithmetic on the 16-bit MFMA; f16x2 needs |values| < 65504), "bf16" (reduced precision)
-        self.precision = os.getenv("EV2H_PRECISION", "f32")
+        # arithmetic of the matrix contractions: "f16x2" (default: fp32-class two-plane fp16 split with exact
+        # per-window range scaling, any checkpoint / input magnitude), "bf16x3" (fp32-class three-plane bf16 split), "f32"
+        # (exact fp32 MFMA), "bf16" (reduced precision)
+        self.precision = os.getenv("EV2H_PRECISION", "f16x2")
         self.left_query_conv = _query_conv()
         self.right_query_conv = _query_conv()
         self._packed = None
@@ -274,7 +275,7 @@ class TEHNetWrapper:
 
     def __init__(self, device, mano_path="../data/models", mano_assets=None, precision=None):
         self.net = TEHNet(n_pose_params=synth.MANO_CMPS).to(device)
-        if precision is not None:           # otherwise EV2H_PRECISION, default "f32"
+        if precision is not None:           # otherwise EV2H_PRECISION, default "f16x2"
             self.net.precision = precision
         self.net.eval()
         self.training = False

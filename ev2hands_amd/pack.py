@@ -288,7 +288,11 @@ class PackedWeights:
         W1f_all, b1_all = np.concatenate(W1f, 0), np.concatenate(b1, 0)
         m.W1f = self._dev(prefix + ".W1f", W1f_all)
         m.b1 = self._dev(prefix + ".b1", b1_all)
-        m.w1f_unscale = plane_unscale(W1f_all, self.ns)        # the table GEMM splits W1f / w1f_unscale on the fly
+        if self.ns and kf >= 32:                               # enc.sa2 (K = 320): plane images, the fast GEMM kernel
+            img, m.w1f_unscale = gemm_bf16_w_image(W1f_all, self.ns)
+            m.W1fs = self._dev_bytes(prefix + ".W1fs", img)
+        else:
+            m.w1f_unscale = plane_unscale(W1f_all, self.ns)    # K = 8 tables run as fp32 fma chains (table_k8_kernel)
         m.w1f_norm = float(np.abs(W1f_all).sum(1).max()) * (1 + 1e-6)
         m.b1_max = float(np.abs(b1_all).max()) * (1 + 1e-6)
 

@@ -278,6 +278,7 @@ typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_ut
     int nbranch;
     ev2h_sa_branch br[3];
     float w1f_unscale;            /* power-of-two plane factor of W1f (ev2h_gemm_desc.w_unscale)       */
+    const void* W1fs;             /* optional 128-row plane images of W1f (kf >= 32: enc.sa2), else NULL */
     float w1f_norm, b1_max;       /* F16X2 range bounds of the table: max row L1 norm of W1f, max |b1| */
 } ev2h_sa_module;
 
