@@ -79,7 +79,7 @@ static inline void prof_end(const char* tag, ev2h_stream_t st) {
 // its own stream on that device.
 struct SideCtx {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
 };
 constexpr int EV2H_MAX_DEVICES = 16;
@@ -94,7 +94,7 @@ static SideCtx* side_ctx() {     // the current device's side stream, or nullptr
         c.state = -1;
         if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess) {
             bool ok = true;
-            for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 8; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
             if (ok) c.state = 1;
         }
     }
@@ -272,9 +272,8 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
 // one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius.
 // Range records (F16X2): feat_amax / feat_amax2 = records of the table's input rows, p1_amax / p1_scale = record and storage scale
 // of the table, out_amax = record of the module's output.
-static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
-                     int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st,
-                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax) {
+static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, int ldf, int B, int Npts, float* P1, ev2h_stream_t st,
+                    const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale) {
     int c1sum = 0;
     float extra = 0.f;                   // max over the branches of |W1x|_1 * radius: what layer 1 adds to a table entry
     for (int i = 0; i < m.nbranch; ++i) {
@@ -292,7 +291,14 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         g.y_amax = p1_amax; g.y_group_rows = Npts;
         g.y_scale = p1_scale; g.y_bound_w = m.w1f_norm; g.y_bound_b = m.b1_max + extra;
     }
-    RUN(ev2h_gemm(&g, st));
+    return ev2h_gemm(&g, st);
+}
+
+static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,
+                       const int32_t* cnt, int B, int Npts, const float* P1, float* out, int ldo, ev2h_stream_t st, bool ranges,
+                       const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax) {
+    int c1sum = 0;
+    for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     int coff1 = 0, coff3 = 0;
     for (int i = 0; i < m.nbranch; ++i) {
         const ev2h_sa_branch& br = m.br[i];
@@ -302,7 +308,7 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
-        if (feat_amax) {
+        if (ranges) {
             d.p1_scale = p1_scale; d.p1_amax = p1_amax; d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
         }
@@ -317,6 +323,13 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
         coff3 += br.C3;
     }
     return EV2H_OK;
+}
+
+static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
+                     int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st,
+                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax) {
+    RUN(sa_table(precision, m, feat, ldf, B, Npts, P1, st, feat_amax, p1_amax, p1_scale));
+    return sa_branches(precision, tag, m, pts4, ctr4, gidx, cnt, B, Npts, P1, out, ldo, st, feat_amax != nullptr, p1_amax, p1_scale, out_amax);
 }
 
 }  // namespace
@@ -367,6 +380,19 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
 
     // ---- input layout + all three samplings of the raw cloud (enc.sa1, left.sa1, right.sa1)
     RUN(ev2h_prep_points(xyz_cm, B, C, N, mhlnes, ws.f("pts4"), ws.f("feat8"), ws.r(R_FEAT), st));
+    // fork 0: the layer-1 table of enc.sa1 needs the prepared input only; it is written (HBM-bound) on the side stream while the
+    // farthest-point sampling (latency-bound, 896 dependent steps) and the ball query run on the caller's stream
+    const bool fork = side != nullptr;
+    static const bool extra = !(getenv("EV2H_EXTRA_OVERLAP") && atoi(getenv("EV2H_EXTRA_OVERLAP")) == 0);   // A/B: table + classifier on the side stream
+    ev2h_stream_t sd = fork ? (ev2h_stream_t)side->stream : st;
+    ev2h_stream_t sx = (fork && extra) ? sd : st;
+    if (fork) {
+        EV2H_CHECK_HIP(hipEventRecord(side->ev[4], (hipStream_t)st));
+        EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[4], 0));
+        *forked = true;
+    }
+    RUN(sa_table(prec, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
+    if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[5], side->stream));
     {
         const int S[3] = {512, 128, 128};
         const int64_t* init[3] = {fps_init, fps_init + 2 * (size_t)B, fps_init + 3 * (size_t)B};
@@ -375,12 +401,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
     }
     // fork 1: both hands' ball queries only need the raw cloud and their centroids
-    const bool fork = side != nullptr;
-    ev2h_stream_t sd = fork ? (ev2h_stream_t)side->stream : st;
     if (fork) {
         EV2H_CHECK_HIP(hipEventRecord(side->ev[0], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[0], 0));
-        *forked = true;
     }
     for (int h = 0; h < 2; ++h) {
         const ev2h_sa_module& m = w->mano_sa1[h];
@@ -398,8 +421,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
-        RUN(sa_module(prec, "sa1", m, ws.f("feat8"), 8, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st,
-                      ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A)));
+        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
+        RUN(sa_branches(prec, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
+                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A)));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
     {
@@ -435,15 +459,22 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));
     RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st, rg(R_FP1H1, N, R_FP1H2, N)));
     RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st, rg(R_FP1H2, N, R_L0, N)));
-    // ---- classifier (TEHNet.py:188)
-    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, st, rg(R_L0, N, R_CLSH, N)));
-    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, st, rg(R_CLSH, N)));
-    RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, st));
+    // ---- classifier (TEHNet.py:188): independent of the query convolutions (both read l0) -- on the side stream, so that its
+    // HBM-bound tail (the 4-column layer, the logits transpose) runs under the k=3 GEMMs
+    if (fork) {
+        EV2H_CHECK_HIP(hipEventRecord(side->ev[6], (hipStream_t)st));
+        EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[6], 0));
+    }
+    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
+    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
+    RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, sx));
+    if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N, R_Q1, N), nullptr, 0, 0, 3, N));
     for (int h = 0; h < 2; ++h)
         RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
     // ---- attention (TEHNet.py:13-27)
+    if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));              // logits ready
     RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
     RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
