@@ -145,18 +145,18 @@ class HipEvents:
 
 
 def pmc_traffic(precision="f32"):
-    """HBM bytes per launch of the profiled kernel from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_hbm_traffic_*.json: (2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction); None if absent."""
+    """(HBM bytes per launch of the profiled kernel, source file) from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_hbm_traffic_*.json: (2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction); (None, None) if absent."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_*.json")))
     if not files:
-        return None
+        return None, None
     try:
         ks = json.load(open(files[-1]))["kernels"]
         k = ks[[n for n in ks if "128, 196, 256" in n][0]]
-        return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch_corrected"], "source": os.path.basename(files[-1])}
+        return k["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def roofline_entry(precision, B, kernel_ms_list):
@@ -167,12 +167,14 @@ def roofline_entry(precision, B, kernel_ms_list):
     peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
     alg_flops = 2.0 * PROFILED_MAC_PER_WINDOW * B
     alg = alg_flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(precision)
     return {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch, {precision})",
             "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
             "accounting": "algorithmic fp32 multiply-adds x 2 / HIP-event kernel time / dense peak of the MFMA type used",
             "executed": round(alg * nprod, 2), "executed_frac": round(alg * nprod / peak, 4), "products_per_mac": nprod,
             "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": pmc_traffic(precision), "kernel_ms": round(kavg, 4), "kernel_samples": len(kernel_ms_list),
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/%s)" % traffic_src if traffic_src else None,
+            "kernel_ms": round(kavg, 4), "kernel_samples": len(kernel_ms_list),
             "flop_per_launch": alg_flops}
 
 
