@@ -141,14 +141,6 @@ struct Layout {
     }
 };
 
-static const char* hname(const char* base, int h) {
-    static thread_local char pool[32][24];
-    static thread_local int cur = 0;
-    char* s = pool[cur++ & 31];
-    snprintf(s, 24, "%s%c", base, h ? 'R' : 'L');
-    return s;
-}
-
 // names with an L/R suffix are stored as literals so Buf::name stays valid
 static const char* const kHandNames[2][10] = {
     {"P1mL", "fpsmL", "ctrmL", "gidxm0L", "gidxm1L", "cntmL", "m1bufL", "msa2hL", "m2L", "fc1L"},
@@ -223,7 +215,6 @@ static void build_layout(Layout& L, int B, int N) {
     }
     L.add("ranges", (size_t)R_COUNT * b);       // F16X2 range records (uint32 [R_COUNT][B]) ...
     L.add("p1scale", 4 * b);                    // ... and the storage scales of the four layer-1 tables (float [4][B])
-    (void)hname;
 }
 
 struct Ws {
@@ -363,7 +354,6 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
                         const int64_t* fps_init, const ev2h_outputs* out, const Ws& ws, ev2h_stream_t st, SideCtx* side, bool* forked) {
     const int R = B * N;
     const int prec = w->precision;
-    const Rng none{};
     auto rg = [&](int xid, int xg, int yid = -1, int yg = 0, int xid2 = -1) {
         Rng r{};
         if (ws.ranges_on) {
@@ -499,7 +489,6 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh, rg(R_FC1 + h, 1)));
         if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
     }
-    (void)none;
     return EV2H_OK;
 }
 

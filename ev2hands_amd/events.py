@@ -90,13 +90,18 @@ class EventWindowBuilderS(EventWindowBuilder):
         if sampling:
             idx = sample_idx if sample_idx is not None else np.stack([np.random.choice(int(m), self.n) for m in ms])
         else:
-            if len(set(int(m) for m in ms)) != 1 and any(int(m) > self.n for m in ms):
+            # erpc.py:220-227: keep all M pixels and append n_events - M resampled ones (n raw events give M <= n pixels)
+            if (ms > self.n).any():
                 raise RuntimeError("sampling=False needs at most n_events unique pixels per window")
             rows = []
-            for b, m in enumerate(ms):
-                m = int(m)
-                extra = (np.asarray(sample_idx[b]) if sample_idx is not None else np.random.choice(m, self.n - m)) if m < self.n else np.zeros(0, dtype=np.int64)
-                rows.append(np.concatenate([np.arange(m), extra]).astype(np.int64))
+            for b, m in enumerate(int(v) for v in ms):
+                if m == self.n:
+                    extra = np.zeros(0, dtype=np.int64)
+                elif sample_idx is not None:
+                    extra = np.asarray(sample_idx[b], dtype=np.int64)
+                else:
+                    extra = np.random.choice(m, self.n - m)
+                rows.append(np.concatenate([np.arange(m, dtype=np.int64), extra]))
             idx = np.stack(rows)
         events, lab = self.sample(sorted_t, counts, idx, labels)
         self.table, self.table_labels = sorted_t, labels
