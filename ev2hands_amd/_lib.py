@@ -35,6 +35,13 @@ class SaDesc(C.Structure):
                 ("out_amax", vp)]
 
 
+class FpDesc(C.Structure):
+    _fields_ = [("T", vp), ("ldt", ci), ("nn_idx", vp), ("nn_w", vp), ("b2", vp), ("b3", vp), ("W2s", vp), ("W3s", vp),
+                ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("out", vp), ("ldo", ci),
+                ("B", ci), ("N", ci), ("S", ci), ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci),
+                ("t_scale", vp), ("t_amax", vp), ("w2_norm", C.c_float), ("b2_max", C.c_float), ("out_amax", vp)]
+
+
 class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_double), ("W2s", vp), ("W3s", vp),
@@ -54,7 +61,7 @@ class Weights(C.Structure):
     _fields_ = [("sa1", SaModule), ("sa2", SaModule), ("mano_sa1", SaModule * 2),
                 ("sa3", Dense * 3),
                 ("fp3_skip", Dense), ("fp3_bcast", Dense), ("fp3_1", Dense),
-                ("fp2", Dense * 2), ("fp1", Dense * 3),
+                ("fp2", Dense * 2), ("fp1", Dense * 3), ("fp1m", SaModule),
                 ("cls0", Dense), ("cls4", Dense),
                 ("qconv0", Dense), ("qconv4", Dense * 2),
                 ("mano_sa2", (Dense * 2) * 2),
@@ -76,7 +83,7 @@ class Outputs(C.Structure):
 EXPORTS = [
     "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
-    "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max",
+    "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp",
     "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
     "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
@@ -107,7 +114,7 @@ def lib() -> C.CDLL:
     L.ev2h_workspace_buffer.restype = vp
     L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
     L.ev2h_struct_sizes.restype = None
-    L.ev2h_struct_sizes.argtypes = [C.c_size_t * 6]
+    L.ev2h_struct_sizes.argtypes = [C.c_size_t * 7]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -116,6 +123,7 @@ def lib() -> C.CDLL:
     L.ev2h_gemm.argtypes = [C.POINTER(GemmDesc), vp]
     L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, vp]
     L.ev2h_sa_mlp_max.argtypes = [C.POINTER(SaDesc), vp]
+    L.ev2h_fp_mlp.argtypes = [C.POINTER(FpDesc), vp]
     L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
     L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
     L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp, vp]
@@ -129,12 +137,12 @@ def lib() -> C.CDLL:
     L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp]
     L.ev2h_collision_penalty.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, C.c_double, vp, vp, ci, vp, vp]
     L.ev2h_profile_set.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), ci]
-    sizes = (C.c_size_t * 6)()
+    sizes = (C.c_size_t * 7)()
     L.ev2h_struct_sizes(sizes)
-    mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs)]
+    mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs, FpDesc)]
     if list(sizes) != mine:
         raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
-    if L.ev2h_abi_version() != 3:      # 3: F16X2 range records (amax arguments, ev2h_gemm_desc / ev2h_sa_desc range fields)
+    if L.ev2h_abi_version() != 4:      # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m
         raise Ev2hError("ABI version mismatch")
     _lib = L
     return L

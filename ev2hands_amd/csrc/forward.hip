@@ -24,13 +24,14 @@ void ev2h_set_error(const char* fmt, ...) {
 extern "C" const char* ev2h_last_error(void) { return g_err; }
 extern "C" int ev2h_abi_version(void) { return EV2H_ABI_VERSION; }
 
-extern "C" void ev2h_struct_sizes(size_t out[6]) {
+extern "C" void ev2h_struct_sizes(size_t out[7]) {
     out[0] = sizeof(ev2h_gemm_desc);
     out[1] = sizeof(ev2h_sa_desc);
     out[2] = sizeof(ev2h_sa_module);
     out[3] = sizeof(ev2h_weights);
     out[4] = sizeof(ev2h_mano_consts);
     out[5] = sizeof(ev2h_outputs);
+    out[6] = sizeof(ev2h_fp_desc);
 }
 
 extern "C" int ev2h_init(void) { return ev2h_gemm_init(); }     // per-device, thread-safe, idempotent (common.hpp: PerDevice)
@@ -152,12 +153,12 @@ enum RangeId {
     R_HF,            // two records: left, right
     R_HF_R,
     R_M1, R_M1_R, R_MSA2H, R_MSA2H_R, R_M2, R_M2_R, R_FC1, R_FC1_R,
-    R_P1A, R_P1B, R_P1M, R_P1M_R,
+    R_P1A, R_P1B, R_P1M, R_P1M_R, R_FP1T,
     R_COUNT
 };
 static const char* const kRangeNames[R_COUNT] = {
     "feat", "l1a", "l1b", "l2", "sa3h1", "sa3h2", "l3", "fp3h", "fp3o", "fp2h", "l1new", "fp1in", "fp1h1", "fp1h2", "l0", "clsh", "q1",
-    "hfL", "hfR", "m1L", "m1R", "msa2hL", "msa2hR", "m2L", "m2R", "fc1L", "fc1R", "p1a", "p1b", "p1mL", "p1mR"};
+    "hfL", "hfR", "m1L", "m1R", "msa2hL", "msa2hR", "m2L", "m2R", "fc1L", "fc1R", "p1a", "p1b", "p1mL", "p1mR", "fp1t"};
 
 static void build_layout(Layout& L, int B, int N) {
     const size_t R = (size_t)B * N;
@@ -187,6 +188,7 @@ static void build_layout(Layout& L, int B, int N) {
     L.add("fp3o", b * 128 * 256);
     L.add("fp2h", b * 512 * 256);
     L.add("l1new", b * 512 * 128);
+    L.add("fp1T", b * 512 * 128);                // 16-bit modes: layer-1 table of fp1 (fp1in / fp1h1 / fp1h2 are then unused)
     L.add("fp1in", R * 128);
     L.add("fp1h1", R * 128);
     L.add("fp1h2", R * 128);
@@ -214,7 +216,7 @@ static void build_layout(Layout& L, int B, int N) {
         L.add(kHandNames[h][9], b * 1024);
     }
     L.add("ranges", (size_t)R_COUNT * b);       // F16X2 range records (uint32 [R_COUNT][B]) ...
-    L.add("p1scale", 4 * b);                    // ... and the storage scales of the four layer-1 tables (float [4][B])
+    L.add("p1scale", 5 * b);                    // ... and the storage scales of the five layer-1 tables (float [5][B])
 }
 
 struct Ws {
@@ -444,11 +446,32 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st, rg(R_L1A, 512, R_FP2H, 512, R_L1B)));
     RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st, rg(R_FP2H, 512, R_L1NEW, 512)));
     // ---- fp1 (TEHNet.py:186): 3-NN 512 -> N, no skip
-    RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
-                             ws.i("nn1_idx"), ws.f("nn1_w"), ws.r(R_FP1IN), st));
-    RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));
-    RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st, rg(R_FP1H1, N, R_FP1H2, N)));
-    RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st, rg(R_FP1H2, N, R_L0, N)));
+    static const bool unfused_fp1 = getenv("EV2H_FP1_UNFUSED") != nullptr;      // A/B switch
+    if (prec != EV2H_PREC_F32 && w->fp1m.W1fs && !unfused_fp1) {
+        // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
+        // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
+        // the two hidden layers (3 x 268 MB written and read back at B = 256) never reach memory
+        const ev2h_sa_module& m = w->fp1m;
+        RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, nullptr, 0, 0, nullptr, 0, ws.i("nn1_idx"), ws.f("nn1_w"), nullptr, st));
+        RUN(sa_table(prec, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
+        ev2h_fp_desc d{};
+        d.T = ws.f("fp1T"); d.ldt = 128; d.nn_idx = ws.i("nn1_idx"); d.nn_w = ws.f("nn1_w");
+        d.b2 = m.br[0].b2; d.b3 = m.br[0].b3; d.W2s = m.br[0].W2s; d.W3s = m.br[0].W3s;
+        d.w2_unscale = m.br[0].w2_unscale; d.w3_unscale = m.br[0].w3_unscale;
+        d.out = ws.f("l0"); d.ldo = 256; d.B = B; d.N = N; d.S = 512; d.C1 = 128; d.C2 = 128; d.C3 = 256; d.precision = prec;
+        if (ws.ranges_on) {
+            d.t_scale = ws.p1scale(4); d.t_amax = ws.r(R_FP1T); d.w2_norm = m.br[0].w2_norm; d.b2_max = m.br[0].b2_max; d.out_amax = ws.r(R_L0);
+        }
+        prof_begin("fp1", st);
+        RUN(ev2h_fp_mlp(&d, st));
+        prof_end("fp1", st);
+    } else {
+        RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
+                                 ws.i("nn1_idx"), ws.f("nn1_w"), ws.r(R_FP1IN), st));
+        RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));
+        RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st, rg(R_FP1H1, N, R_FP1H2, N)));
+        RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st, rg(R_FP1H2, N, R_L0, N)));
+    }
     // ---- classifier (TEHNet.py:188): independent of the query convolutions (both read l0) -- on the side stream, so that its
     // HBM-bound tail (the 4-column layer, the logits transpose) runs under the k=3 GEMMs
     if (fork) {

@@ -36,6 +36,9 @@ struct SaBP {
     const float* p1_scale; const unsigned* p1_amax;   // per window: power of two the P1 table was stored with, max |stored P1|
     float w1x_norm, dmax, w2_norm, b2_max;
     unsigned* out_amax;                    // per window: atomicMax of |out|
+    // ROWS (feature propagation, ev2h_fp_mlp): a "group" is a strip of 32 consecutive points of a window; P1 is the coarse points'
+    // layer-1 table, the row of a point is the 3-NN blend of three table rows; out holds one row per point
+    const int32_t* nn_idx; const float* nn_w; int N;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -81,8 +84,11 @@ struct SaBCfg {
 //              persistent workgroup whose waves then walk their groups with NO barrier and no DMA in the loop -- the
 //              waves drift apart, so one wave's split (VALU) phases run under the other waves' MFMA phases, and a tile
 //              step no longer pays the DMA issue / wait / barrier that dominate when a tile holds only 6-18 MFMAs.
-template <int C1, int C2, int C3, int NS, bool RES>
+// ROWS = true (streamed only): the feature-propagation chain of ev2h_fp_mlp -- same tile walk, but layer 1 is the inverse-distance
+//              blend of three table rows (no relative xyz) and the layer-3 tiles are written out row by row instead of maximised.
+template <int C1, int C2, int C3, int NS, bool RES, bool ROWS = false>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
+    static_assert(!(RES && ROWS), "the row-output variant streams its tiles");
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
@@ -99,10 +105,12 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
 
-    for (int i = tid; i < C1; i += SAB_THREADS) {
-        const float4 w = p.W1x[i];
-        float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
-        d[0] = w.x; d[4] = w.y; d[8] = w.z;
+    if constexpr (!ROWS) {
+        for (int i = tid; i < C1; i += SAB_THREADS) {
+            const float4 w = p.W1x[i];
+            float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
+            d[0] = w.x; d[4] = w.y; d[8] = w.z;
+        }
     }
     for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
 
@@ -142,8 +150,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
     for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
 
-    const float4 ctr = p.ctr4[gg];
-    const int32_t* gi = p.gidx + (size_t)gg * p.K;
+    float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t* gi = nullptr;
+    if constexpr (!ROWS) { ctr = p.ctr4[gg]; gi = p.gidx + (size_t)gg * p.K; }
+    const int row0 = ROWS ? (gg - b * p.S) * 32 : 0;          // ROWS: first point of this strip inside its window
+    float b3r[ROWS ? T3 : 1];
+    if constexpr (ROWS) {
+#pragma unroll
+        for (int u = 0; u < T3; ++u) b3r[u] = p.b3[32 * u + l31];
+    }
+    unsigned am = 0u;
     // f16x2 range: with P1' = s1 P1 (table stored scaled) and d' = s1 d the layer-1 output is H1' = s1 H1 <= a1 + s1 |W1x|_1 dmax
     // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
@@ -165,10 +181,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
     // workgroup's longest group (DMA pieces and barriers), without computing.
-    int my_strips = p.K >> 5;
-    if (p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
+    int my_strips = ROWS ? 1 : p.K >> 5;
+    if (!ROWS && p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
     int nstrips = my_strips;
-    if constexpr (!RES) {
+    if constexpr (!RES && !ROWS) {
         int* s_strips = reinterpret_cast<int*>(smem + WBYTES + C1 * 16 + T2 * 32 * 4);
         if (tid == 0) *s_strips = 1;
         __syncthreads();
@@ -198,14 +214,45 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 continue;
             }
         }
-        const int idx = gi[strip * 32 + l31];
-        const float4 q = p.pts4[(size_t)b * p.Npts + idx];
-        float dx = __fsub_rn(q.x, ctr.x), dy = __fsub_rn(q.y, ctr.y), dz = __fsub_rn(q.z, ctr.z);
-        if constexpr (NS == 2) { dx *= s1; dy *= s1; dz *= s1; }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
-        const float4* prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        const float4* prow = nullptr;
+        const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
+        float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
         f32x4 raw[4];
+        // ROWS: raw = (w0 T0 + w1 T1) + w2 T2 of chunk c (pointnet2_utils.py:303 applied to the layer-1 table; the table is stored
+        // scaled by s1 in F16X2, so the blend is s1 H1 before the ReLU)
+        f32x4 trw[ROWS ? 3 : 1][4];
+        auto fetch = [&](int c) {                   // issue the loads of chunk c's three table rows
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+            for (int j = 0; j < (ROWS ? 3 : 1); ++j)
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + j4);
+        };
+        auto blend = [&]() {
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    raw[j4][e] = __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
+        };
+        if constexpr (ROWS) {
+            const size_t gr = ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * 3;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                trow[j] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + p.nn_idx[gr + j]) * p.ldp + 16 * half);
+                tw[j] = p.nn_w[gr + j];
+            }
+            fetch(0);
+            blend();
+        } else {
+            const int idx = gi[strip * 32 + l31];
+            const float4 q = p.pts4[(size_t)b * p.Npts + idx];
+            dx = __fsub_rn(q.x, ctr.x); dy = __fsub_rn(q.y, ctr.y); dz = __fsub_rn(q.z, ctr.z);
+            if constexpr (NS == 2) { dx *= s1; dy *= s1; dz *= s1; }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
+            prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+        }
 
         // ---------------- layer 2 (contraction-chunk outer): h2[t] = D2[channel 32t + mfma_row(r,half)][neighbour]
         // (the accumulators start at the b2 bias: D rows 4j..4j+3 of a lane are 4 consecutive channels)
@@ -231,7 +278,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             if constexpr (!RES) {
                 if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
             }
-            if (!Cfg::PREFETCH_P1 && c > 0) {
+            if (!ROWS && !Cfg::PREFETCH_P1 && c > 0) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
             }
@@ -243,7 +290,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 const f32x4 wx = wp[0], wy = wp[1], wz = wp[2];
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
+                for (int e = 0; e < 4; ++e)
+                    v[e] = ROWS ? raw[j4][e] : __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
                 unsigned lo[NS], hi[NS];
                 if constexpr (NS == 2) {
                     split_planes<NS>(relu_sat_f16(v[0]), relu_sat_f16(v[1]), lo);
@@ -258,7 +306,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
                 }
             }
-            if (Cfg::PREFETCH_P1 && c + 1 < NC1) {
+            if constexpr (ROWS) {
+                if (c + 1 < NC1) fetch(c + 1);      // in flight under this chunk's MFMAs, blended after them
+            } else if (Cfg::PREFETCH_P1 && c + 1 < NC1) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
             }
@@ -281,6 +331,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     h2[t0] = mfma_planes<NS>(a0[PL::A[j]], bp[m0][PL::B[j]], h2[t0]);
                     h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
                 }
+            }
+            if constexpr (ROWS) {
+                if (c + 1 < NC1) blend();
             }
             STAMP(4 + 4 * c);
             if constexpr (!RES) {
@@ -350,12 +403,30 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             STAMP(41 + 4 * u);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+            if constexpr (ROWS) {
+                // D3[point][channel]: this lane holds channel 32u + l31 of the points 8(r/4) + 4 half + r%4 -- one store
+                // instruction writes two 128-byte row segments
+                float b3u = b3r[0];
+#pragma unroll
+                for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
+                float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pt = 8 * (r >> 2) + (r & 3);
+                    const float o = fmaxf(acc[r] * c3 + b3u, 0.f);
+                    if (valid && row0 + 4 * half + pt < p.N) {
+                        orow[(size_t)pt * p.ldo] = o;
+                        am = max(am, __float_as_uint(o));
+                    }
+                }
+            } else {
             float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
             mx = fmaxf(mx, acc[15]);
 #pragma unroll
             for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
+            }
             STAMP(42 + 4 * u);
             if constexpr (!RES) {
                 if (u % UPT == UPT - 1) {
@@ -369,14 +440,15 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         STAMP(37);
     }
 
-    unsigned am = 0u;
+    if constexpr (!ROWS) {
 #pragma unroll
-    for (int u = 0; u < T3; ++u) {
-        const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
-        if (valid && half == 0) {
-            const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
-            p.out[(size_t)g * p.ldo + 32 * u + l31] = o;
-            am = max(am, __float_as_uint(o));
+        for (int u = 0; u < T3; ++u) {
+            const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
+            if (valid && half == 0) {
+                const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
+                p.out[(size_t)g * p.ldo + 32 * u + l31] = o;
+                am = max(am, __float_as_uint(o));
+            }
         }
     }
     if constexpr (NS == 2) {
@@ -442,6 +514,47 @@ extern "C" int ev2h_sab_timeline_read(long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sab_timeline), sizeof(long long) * 256);
 }
 #endif
+template <int NS>
+static int launch_fp(SaBP p, hipStream_t st) {
+    using Cfg = SaBCfg<128, 128, 256, NS>;
+    auto k = sa_mlp_max_bf16_kernel<128, 128, 256, NS, false, true>;
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
+    k<<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(d && d->T && d->nn_idx && d->nn_w && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
+    EV2H_CHECK_ARG(d->B > 0 && d->N > 0 && d->S >= 3 && d->ldt >= d->C1 && (d->ldt % 4) == 0 && d->ldo >= d->C3);
+    if (d->C1 != 128 || d->C2 != 128 || d->C3 != 256) {
+        ev2h_set_error("ev2h_fp_mlp: unsupported MLP widths %d-%d-%d (128-128-256 only)", d->C1, d->C2, d->C3);
+        return EV2H_ERR_ARG;
+    }
+    SaBP p{};
+    p.P1 = d->T; p.ldp = d->ldt; p.nn_idx = d->nn_idx; p.nn_w = d->nn_w; p.N = d->N;
+    p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
+    p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
+    p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
+    p.nblk = ceil_div(d->B * p.S, SAB_WAVES);
+    if (d->precision == EV2H_PREC_F16X2) {
+        p.out_amax = d->out_amax;
+        if (d->t_scale) {
+            EV2H_CHECK_ARG(d->t_amax && d->w2_norm >= 0.f && d->b2_max >= 0.f);
+            // a convex blend of table rows stays inside the table's range (+ rounding): the layer-1 bound is the table's record
+            p.p1_scale = d->t_scale; p.p1_amax = d->t_amax; p.w1x_norm = 0.f; p.dmax = 1.f; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
+        }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (d->precision == EV2H_PREC_BF16X3) return launch_fp<3>(p, st);
+    if (d->precision == EV2H_PREC_F16X2) return launch_fp<2>(p, st);
+    if (d->precision == EV2H_PREC_BF16) return launch_fp<1>(p, st);
+    ev2h_set_error("ev2h_fp_mlp: precision %d is not a 16-bit plane mode (F32: ev2h_three_nn_interp + ev2h_gemm)", d->precision);
+    return EV2H_ERR_ARG;
+}
+
 // called by ev2h_sa_mlp_max when d->precision != EV2H_PREC_F32
 int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d->W2s && d->W3s);

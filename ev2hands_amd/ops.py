@@ -170,6 +170,47 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     return out
 
 
+def feature_propagation(xyz1: torch.Tensor, xyz2: torch.Tensor, points2: torch.Tensor, W1, b1, W2, b2, W3, b3, precision: str = "f16x2",
+                        ranges: bool = False, x_amax=None, out_amax=None):
+    """PointNetFeaturePropagation.forward with points1 = None and a three-layer MLP (pointnet2_utils.py:280-316, fp1 of
+    TEHNet.py:129,186) in the fused form of the 16-bit path: 3-NN search (ev2h_three_nn_interp without output), layer-1 table of the
+    S coarse points (ev2h_gemm), blend + layers 2-3 (ev2h_fp_mlp).  xyz1 [B,N,3], xyz2 [B,S,3], points2 [B,S,D]; W*, b* the folded
+    fp32 weights (128-128-256).  ranges=True: F16X2 range handling (x_amax = record [B] of points2, out_amax = record of the output).
+    Returns (out [B,N,C3], idx [B,N,3], weight [B,N,3])."""
+    from .pack import NS_OF, sa_bf16_images
+    B, N, _ = xyz1.shape
+    S, D = xyz2.shape[1], points2.shape[2]
+    dev = xyz1.device
+    C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+    p1, p2 = pack_points(xyz1), pack_points(xyz2)
+    idx = torch.empty(B, N, 3, device=dev, dtype=torch.int32)
+    w = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    _lib.check(L.ev2h_three_nn_interp(p1.data_ptr(), p2.data_ptr(), B, N, S, None, 0, 0, None, 0, idx.data_ptr(), w.data_ptr(), None, _st()),
+               "ev2h_three_nn_interp")
+    t_scale = t_amax = None
+    if ranges:
+        t_scale = torch.empty(B, device=dev, dtype=torch.float32)
+        t_amax = range_record(B, dev)
+    T = dense(points2.reshape(B * S, D).contiguous(), W1.contiguous(), b1, precision=precision,
+              x_amax=x_amax if ranges else None, x_group_rows=S if ranges else 0, y_amax=t_amax, y_group_rows=S if ranges else 0,
+              y_scale=t_scale, y_bound_w=float(W1.abs().sum(1).max()) * (1 + 1e-6), y_bound_b=float(b1.abs().max()) * (1 + 1e-6))
+    out = torch.empty(B, N, C3, device=dev, dtype=torch.float32)
+    i2, i3, u2, u3 = sa_bf16_images(W2.detach().cpu().double().numpy(), W3.detach().cpu().double().numpy(), NS_OF[precision])
+    keep = [torch.from_numpy(i2).to(dev), torch.from_numpy(i3).to(dev), b2.contiguous(), b3.contiguous()]
+    d = _lib.FpDesc()
+    d.T, d.ldt, d.nn_idx, d.nn_w = T.data_ptr(), C1, idx.data_ptr(), w.data_ptr()
+    d.b2, d.b3, d.W2s, d.W3s, d.w2_unscale, d.w3_unscale = keep[2].data_ptr(), keep[3].data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), u2, u3
+    d.out, d.ldo, d.B, d.N, d.S, d.C1, d.C2, d.C3 = out.data_ptr(), C3, B, N, S, C1, C2, C3
+    d.precision = _lib.PREC[precision]
+    if ranges:
+        d.t_scale, d.t_amax = t_scale.data_ptr(), t_amax.data_ptr()
+        d.w2_norm, d.b2_max = float(W2.abs().sum(1).max()) * (1 + 1e-6), float(b2.abs().max()) * (1 + 1e-6)
+        d.out_amax = _lib.ptr(out_amax)
+    _lib.check(L.ev2h_fp_mlp(C.byref(d), _st()), "ev2h_fp_mlp")
+    return out, idx.long(), w
+
+
 def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor, hf_amax: torch.Tensor | None = None):
     """TEHNet.py:13-27 for both hands.  logits_pm [B,N,4], query_pm [2,B,N,256], value_pm [B,N,256]
     -> (sim [B,2,4,256], hf8 [2,B,N,8]).  hf_amax: optional range records [2,B] of the context features."""

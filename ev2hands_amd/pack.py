@@ -198,6 +198,8 @@ class PackedWeights:
         for k in range(3):
             W, b = _fold(sd, f"fp1.mlp_convs.{k}", f"fp1.mlp_bns.{k}")
             self._dense(w.fp1[k], f"fp1.{k}", W[:, :, 0], b)
+        if self.ns:
+            self._fp_module(w.fp1m, sd, "fp1")
         a, be = _bn_affine(sd, "classifier.2")
         self._dense(w.cls0, "cls0", _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be)
         self._dense(w.cls4, "cls4", _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
@@ -255,6 +257,36 @@ class PackedWeights:
                 assert W.shape[1] == 515
                 W = np.concatenate([W[:, 3:], W[:, :3], np.zeros((W.shape[0], 5))], 1)
             self._dense(arr[k], f"{prefix}.{k}", W, b)
+
+    def _fp_module(self, m, sd, prefix):
+        """A three-layer feature-propagation MLP without skip input (fp1, TEHNet.py:129) in the form ev2h_fp_mlp takes: the first
+        layer as a table over the coarse points (W1f, b1 -- it commutes with the interpolation), layers 2-3 as the tile images of
+        the fused set-abstraction kernel."""
+        Ws, bs = [], []
+        for j in range(3):
+            W, b = _fold(sd, f"{prefix}.mlp_convs.{j}", f"{prefix}.mlp_bns.{j}")
+            Ws.append(W[:, :, 0])
+            bs.append(b)
+        C1, C2, C3 = (x.shape[0] for x in Ws)
+        m.kf, m.npoint, m.nbranch = Ws[0].shape[1], 0, 1
+        assert (C1, C2, C3) == (128, 128, 256) and m.kf % 32 == 0
+        br = m.br[0]
+        n = prefix + "m"
+        br.b2 = self._dev(n + ".b2", bs[1])
+        br.b3 = self._dev(n + ".b3", bs[2])
+        br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, 32, 0.0
+        br.w1x_norm = 0.0
+        br.w2_norm = float(np.abs(Ws[1]).sum(1).max()) * (1 + 1e-6)
+        br.b2_max = float(np.abs(bs[1]).max()) * (1 + 1e-6)
+        i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(Ws[1], Ws[2], self.ns)
+        br.W2s = self._dev_bytes(n + ".W2s", i2)
+        br.W3s = self._dev_bytes(n + ".W3s", i3)
+        m.W1f = self._dev(n + ".W1f", Ws[0])
+        m.b1 = self._dev(n + ".b1", bs[0])
+        img, m.w1f_unscale = gemm_bf16_w_image(Ws[0], self.ns)
+        m.W1fs = self._dev_bytes(n + ".W1fs", img)
+        m.w1f_norm = float(np.abs(Ws[0]).sum(1).max()) * (1 + 1e-6)
+        m.b1_max = float(np.abs(bs[0]).max()) * (1 + 1e-6)
 
     def _sa_module(self, m, sd, prefix, nfeat, kf, npoint, radii, nsamples):
         W1f, b1 = [], []

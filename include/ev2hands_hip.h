@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 3
+#define EV2H_ABI_VERSION 4
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -57,8 +57,8 @@ int ev2h_abi_version(void);
 const char* ev2h_last_error(void);
 /* One-time per-process setup (raises dynamic-LDS limits of the big-tile kernels). Idempotent. */
 int ev2h_init(void);
-/* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs]. */
-void ev2h_struct_sizes(size_t out[6]);
+/* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp]. */
+void ev2h_struct_sizes(size_t out[7]);
 
 /* ---- point-set operators --------------------------------------------------------------------- */
 /* [B,C,N] channel-major input -> pts4 [B][N][4] = (x, y, z, (x*x+y*y)+z*z) and feat8 [B][N][8]
@@ -173,6 +173,34 @@ typedef struct ev2h_sa_desc {
     uint32_t* out_amax;          /* [B] range record of `out` (atomicMax), optional                                     */
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
+
+/* ---- fused feature propagation (model/pointnet2_utils.py:296-316 with points1 = None: TEHNet.py:186) --------------
+ * out[b][n] = relu(W3' relu(W2' relu(sum_j w[b][n][j] T[b][idx[b][n][j]]) + b2') + b3'),   T = W1' points2 + b1' per coarse point:
+ * the first Conv1d commutes with the 3-NN interpolation (a row's weights sum to 1 up to rounding, so carrying b1' inside the
+ * table changes a value by <= 2e-7 |b1'|), which makes layer 1 a table over the S coarse points instead of a GEMM over the N
+ * fine ones, and layers 2-3 run in registers like ev2h_sa_mlp_max -- the interpolated rows and both hidden layers never
+ * reach memory.  nn_idx / nn_w as written by ev2h_three_nn_interp.  16-bit plane precisions only (EV2H_PREC_F32: use
+ * ev2h_three_nn_interp + ev2h_gemm); (C1, C2, C3) = (128, 128, 256). */
+typedef struct ev2h_fp_desc {
+    const float* T; int ldt;      /* [B][S][ldt] layer-1 table of the coarse points, C1 columns used (ldt % 4 == 0)     */
+    const int32_t* nn_idx;        /* [B][N][3]                                                                        */
+    const float* nn_w;            /* [B][N][3]                                                                        */
+    const float* b2;              /* [C2]                                                                             */
+    const float* b3;              /* [C3]                                                                             */
+    const void* W2s;              /* tile images as in ev2h_sa_desc                                                   */
+    const void* W3s;
+    float w2_unscale, w3_unscale;
+    float* out; int ldo;          /* [B][N][ldo], C3 columns written                                                  */
+    int B, N, S;
+    int C1, C2, C3;
+    int precision;
+    /* F16X2 range (optional, as in ev2h_sa_desc): the table arrives scaled by the power of two t_scale[b] (ev2h_gemm y_scale) */
+    const float* t_scale;         /* [B]; NULL = unscaled table, no range handling                                    */
+    const uint32_t* t_amax;       /* [B] max |stored T_b|                                                             */
+    float w2_norm, b2_max;
+    uint32_t* out_amax;           /* [B] range record of `out`, optional                                              */
+} ev2h_fp_desc;
+int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
 
 /* ---- attention (model/TEHNet.py:13-27) ------------------------------------------------------------ */
 /* sim[b][h][c][d] = softmax_c( 256^-0.5 * sum_n logits[b][n][c] * query_h[b][n][d] ); query of hand h
@@ -296,6 +324,8 @@ typedef struct ev2h_weights {
     ev2h_dense fp3_skip, fp3_bcast, fp3_1;       /* 1536 split into 512 (skip) + 1024 (broadcast l3)   */
     ev2h_dense fp2[2];
     ev2h_dense fp1[3];
+    ev2h_sa_module fp1m;                         /* fp1 once more in the form ev2h_fp_mlp takes (16-bit precisions): W1f/b1 = table
+                                                    layer, br[0] = layers 2-3 (W1x unused); kf = 128, nbranch = 1               */
     ev2h_dense cls0, cls4;
     ev2h_dense qconv0;                           /* both hands, O = 512, 3 taps                        */
     ev2h_dense qconv4[2];

@@ -95,6 +95,45 @@ def test_three_nn_interp(kind, N1, N2, D):
     assert rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("kind,B,N1,N2,mag", [("E", 2, 2048, 512, 1.0), ("U", 3, 1000, 512, 1.0), ("E", 1, 130, 128, 1.0),
+                                              ("E", 2, 2048, 512, 3e-5), ("E", 2, 2048, 512, 4e5)])
+def test_feature_propagation_fused(kind, B, N1, N2, mag, precision, tol):
+    """ev2h_fp_mlp (3-NN blend of layer-1 table rows + layers 2-3 in one kernel) against the reference's order of operations
+    -- interpolate, then three Conv1d+ReLU (pointnet2_utils.py:296-316) -- in float64.  Ragged N (1000, 130: partial strips),
+    and input magnitudes that need the F16X2 range handling (mag != 1: with records; the hidden layers scale with the input)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    from oracle import tehnet_oracle as O
+    xyz1 = cloud_xyz(kind, B, N1, 41)
+    fps = O.farthest_point_sample(xyz1, N2, torch.zeros(B, dtype=torch.long))
+    xyz2 = O.gather_points(xyz1, fps)
+    f2 = torch.from_numpy(synth.hash_normal("f2", (B, N2, 128), 5)).float() * mag
+    f2[B - 1] *= 0.01                                         # windows of different magnitude in one batch
+    Ws = [torch.from_numpy(synth.hash_normal(f"W{i}", (o, k), 6 + i) / np.sqrt(k)).float() for i, (o, k) in enumerate(((128, 128), (128, 128), (256, 128)))]
+    bs = [torch.from_numpy(synth.hash_normal(f"b{i}", (o,), 9 + i) * 0.1).float() * mag for i, o in enumerate((128, 128, 256))]
+    ranges = precision == "f16x2"
+    x_amax = out_amax = None
+    if ranges:
+        x_amax = ops.range_record(B, "cuda")
+        x_amax.copy_(f2.abs().amax(dim=(1, 2)).view(torch.int32).cuda())
+        out_amax = ops.range_record(B, "cuda")
+    cu = lambda t: t.cuda()                                   # noqa: E731
+    out, gi, gw = ops.feature_propagation(cu(xyz1), cu(xyz2), cu(f2), cu(Ws[0]), cu(bs[0]), cu(Ws[1]), cu(bs[1]), cu(Ws[2]), cu(bs[2]),
+                                          precision=precision, ranges=ranges, x_amax=x_amax, out_amax=out_amax)
+    # the neighbour search itself is test_three_nn_interp's subject (and event clouds hold duplicate points: equal distances, whose
+    # order the reference leaves to an unstable sort) -- here the weights must match and the blend is checked with the kernel's own choice
+    _, w = O.three_nn_weights(xyz1, xyz2)
+    assert rel(gw, w) < 1e-5
+    h = (O.gather_points(f2, gi.cpu()).double() * gw.cpu().double().view(B, N1, 3, 1)).sum(dim=2)
+    for W, b in zip(Ws, bs):
+        h = torch.relu(h @ W.double().T + b.double())
+    for b in range(B):                                        # per window: a window's accuracy must not depend on its neighbours
+        assert rel(out[b], h[b].float()) < tol, (b, rel(out[b], h[b].float()))
+    if ranges:
+        assert torch.equal(ops.range_values(out_amax).cpu(), out.abs().amax(dim=(1, 2)).cpu())
+
+
 GEMM_CASES = [
     # M,   N,   K,  relu, post, taps, rowmax, group
     (256, 128, 128, True, False, 1, 0, 0),

@@ -94,7 +94,7 @@ def test_range_records_hold_the_exact_maxima():
     dbg = net.net.debug_buffer
     for rec, buf, shape, cols in (("l0", "l0", (B, N, 256), slice(0, 256)), ("l1a", "l1cat", (B, 512, 576), slice(0, 320)),
                                   ("l1b", "l1cat", (B, 512, 576), slice(320, 576)), ("l2", "l2buf", (B, 128, 520), slice(0, 512)),
-                                  ("q1", "q1", (B, N, 512), slice(0, 512)), ("fp1in", "fp1in", (B, N, 128), slice(0, 128)),
+                                  ("q1", "q1", (B, N, 512), slice(0, 512)), ("l1new", "l1new", (B, 512, 128), slice(0, 128)),
                                   ("l3", "l3", (B, 1, 1024), slice(0, 1024)), ("fc1L", "fc1L", (B, 1, 1024), slice(0, 1024)),
                                   ("feat", "feat8", (B, N, 8), slice(0, 8)), ("hfR", "hf8", (2, B, N, 8), None)):
         got = dbg("rng." + rec).view(torch.float32)[:B]
@@ -102,9 +102,9 @@ def test_range_records_hold_the_exact_maxima():
         want = t[1].abs().amax((1, 2)) if cols is None else t[:, :, cols].abs().amax((1, 2))
         assert torch.equal(got, want), (rec, got, want)
     # layer-1 tables are stored scaled: scale * (max |table| + |W1x|_1 r) stays below 2^15 and the record is the stored maximum
-    ps = dbg("p1scale").view(4, B)
+    ps = dbg("p1scale").view(5, B)
     for k, (rec, buf, shape) in enumerate((("p1a", "P1a", (B, N, 160)), ("p1b", "P1b", (B, 512, 256)), ("p1mL", "P1mL", (B, N, 256)),
-                                           ("p1mR", "P1mR", (B, N, 256)))):
+                                           ("p1mR", "P1mR", (B, N, 256)), ("fp1t", "fp1T", (B, 512, 128)))):
         got = dbg("rng." + rec).view(torch.float32)[:B]
         want = dbg(buf).view(shape).abs().amax((1, 2))
         assert torch.equal(got, want), rec

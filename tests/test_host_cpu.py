@@ -31,11 +31,11 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_and_abi_version(built):
-    sizes = (C.c_size_t * 6)()
+    sizes = (C.c_size_t * 7)()
     built.ev2h_struct_sizes(sizes)
-    mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs)]
+    mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 3
+    assert built.ev2h_abi_version() == 4
 
 
 def test_workspace_size_grows_linearly(built):
@@ -52,6 +52,8 @@ def test_bad_arguments_return_error_codes_not_crashes(built):
     assert b"bad argument" in built.ev2h_last_error()
     s = _lib.SaDesc()
     assert built.ev2h_sa_mlp_max(C.byref(s), None) != 0
+    f = _lib.FpDesc()
+    assert built.ev2h_fp_mlp(C.byref(f), None) != 0
 
 
 def test_checkpoint_schema():
