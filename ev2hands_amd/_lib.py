@@ -39,7 +39,8 @@ class FpDesc(C.Structure):
     _fields_ = [("T", vp), ("ldt", ci), ("nn_idx", vp), ("nn_w", vp), ("b2", vp), ("b3", vp), ("W2s", vp), ("W3s", vp),
                 ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("out", vp), ("ldo", ci),
                 ("B", ci), ("N", ci), ("S", ci), ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci),
-                ("t_scale", vp), ("t_amax", vp), ("w2_norm", C.c_float), ("b2_max", C.c_float), ("out_amax", vp)]
+                ("t_scale", vp), ("t_amax", vp), ("w2_norm", C.c_float), ("b2_max", C.c_float), ("out_amax", vp),
+                ("out_cols", ci), ("no_relu_out", ci), ("out_cm", vp)]
 
 
 class SaBranch(C.Structure):
@@ -62,7 +63,7 @@ class Weights(C.Structure):
                 ("sa3", Dense * 3),
                 ("fp3_skip", Dense), ("fp3_bcast", Dense), ("fp3_1", Dense),
                 ("fp2", Dense * 2), ("fp1", Dense * 3), ("fp1m", SaModule),
-                ("cls0", Dense), ("cls4", Dense),
+                ("cls0", Dense), ("cls4", Dense), ("clsm", SaBranch),
                 ("qconv0", Dense), ("qconv4", Dense * 2),
                 ("mano_sa2", (Dense * 2) * 2),
                 ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci)]

@@ -478,9 +478,23 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         EV2H_CHECK_HIP(hipEventRecord(side->ev[6], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[6], 0));
     }
-    RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
-    RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
-    RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, sx));
+    static const bool unfused_cls = getenv("EV2H_CLS_UNFUSED") != nullptr;      // A/B switch
+    if (prec != EV2H_PREC_F32 && w->clsm.W2s && !unfused_cls) {
+        // 16-bit modes: both layers in one row-chain kernel -- the 256-wide hidden layer (537 MB at B = 256) never reaches memory,
+        // and the logits are written point-major (for the attention) and channel-major (the output) by the same kernel
+        const ev2h_sa_branch& c = w->clsm;
+        ev2h_fp_desc d{};
+        d.T = ws.f("l0"); d.ldt = 256; d.b2 = c.b2; d.b3 = c.b3; d.W2s = c.W2s; d.W3s = c.W3s;
+        d.w2_unscale = c.w2_unscale; d.w3_unscale = c.w3_unscale;
+        d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits;
+        d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec;
+        if (ws.ranges_on) { d.t_amax = ws.r(R_L0); d.w2_norm = c.w2_norm; d.b2_max = c.b2_max; }
+        RUN(ev2h_fp_mlp(&d, sx));
+    } else {
+        RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
+        RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
+        RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, sx));
+    }
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N, R_Q1, N), nullptr, 0, 0, 3, N));

@@ -39,6 +39,10 @@ struct SaBP {
     // ROWS (feature propagation, ev2h_fp_mlp): a "group" is a strip of 32 consecutive points of a window; P1 is the coarse points'
     // layer-1 table, the row of a point is the 3-NN blend of three table rows; out holds one row per point
     const int32_t* nn_idx; const float* nn_w; int N;
+    // MODE 2 (plain row chain, e.g. the segmentation head): P1 holds the N input rows themselves (no blend, no layer-1 ReLU; F16X2:
+    // scaled here by the power of two of p1_amax); ncols = leading columns of the last tile that are written; relu_out = 0 drops
+    // the last ReLU; out_cm = optional second copy of the output, channel-major [B][ncols][N]
+    int ncols; int relu_out; float* out_cm;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -84,11 +88,13 @@ struct SaBCfg {
 //              persistent workgroup whose waves then walk their groups with NO barrier and no DMA in the loop -- the
 //              waves drift apart, so one wave's split (VALU) phases run under the other waves' MFMA phases, and a tile
 //              step no longer pays the DMA issue / wait / barrier that dominate when a tile holds only 6-18 MFMAs.
-// ROWS = true (streamed only): the feature-propagation chain of ev2h_fp_mlp -- same tile walk, but layer 1 is the inverse-distance
-//              blend of three table rows (no relative xyz) and the layer-3 tiles are written out row by row instead of maximised.
-template <int C1, int C2, int C3, int NS, bool RES, bool ROWS = false>
+// MODE = 1, 2 (streamed only): the row chains of ev2h_fp_mlp -- same tile walk, but the layer-3 tiles are written out row by row
+//              instead of maximised, and layer 1 is (1) the inverse-distance blend of three table rows (no relative xyz) or (2) the
+//              input row itself.
+template <int C1, int C2, int C3, int NS, bool RES, int MODE = 0>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
-    static_assert(!(RES && ROWS), "the row-output variant streams its tiles");
+    constexpr bool ROWS = MODE != 0, DIRECT = MODE == 2;
+    static_assert(!(RES && ROWS), "the row-output variants stream their tiles");
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
@@ -165,10 +171,12 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
     float s1 = 1.f, c2 = p.u2, c3 = p.u3;
     if constexpr (NS == 2) {
-        if (p.p1_scale) {
-            s1 = p.p1_scale[b];
+        if (p.p1_amax) {
+            float a1 = __uint_as_float(p.p1_amax[b]);
+            if constexpr (DIRECT) { s1 = f16x2_scale(p.p1_amax[b]); a1 *= s1; }       // unscaled input rows: scaled as they are read
+            else s1 = p.p1_scale[b];
             const float inv_s1 = pow2_inverse(s1);
-            const float bh1 = __uint_as_float(p.p1_amax[b]) + s1 * (p.w1x_norm * p.dmax);
+            const float bh1 = a1 + s1 * (p.w1x_norm * p.dmax);
             const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bh1 * inv_s1, p.b2_max)));
             c2 = p.u2 * s2 * inv_s1;
             c3 = p.u3 * pow2_inverse(s2);
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         f32x4 trw[ROWS ? 3 : 1][4];
         auto fetch = [&](int c) {                   // issue the loads of chunk c's three table rows
 #pragma unroll
-            for (int j = 0; j < (ROWS ? 3 : 1); ++j)
+            for (int j = 0; j < ((ROWS && !DIRECT) ? 3 : 1); ++j)
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + j4);
         };
@@ -233,9 +241,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    raw[j4][e] = __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
+                    raw[j4][e] = DIRECT ? ((NS == 2) ? trw[0][j4][e] * s1 : trw[0][j4][e])
+                                        : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
-        if constexpr (ROWS) {
+        if constexpr (DIRECT) {
+            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp + 16 * half);
+            fetch(0);
+            blend();
+        } else if constexpr (ROWS) {
             const size_t gr = ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -293,7 +306,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 for (int e = 0; e < 4; ++e)
                     v[e] = ROWS ? raw[j4][e] : __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
                 unsigned lo[NS], hi[NS];
-                if constexpr (NS == 2) {
+                if constexpr (DIRECT) {                  // the rows are the layer's input as it is (|v| < 2^15 by the scale)
+                    split_planes<NS>(v[0], v[1], lo);
+                    split_planes<NS>(v[2], v[3], hi);
+                } else if constexpr (NS == 2) {
                     split_planes<NS>(relu_sat_f16(v[0]), relu_sat_f16(v[1]), lo);
                     split_planes<NS>(relu_sat_f16(v[2]), relu_sat_f16(v[3]), hi);
                 } else {
@@ -410,13 +426,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
                 float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
+                const bool colok = valid && (32 * u + l31 < p.ncols);
+                float* ocm = p.out_cm ? p.out_cm + ((size_t)b * p.ncols + 32 * u + l31) * p.N + row0 + 4 * half : nullptr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pt = 8 * (r >> 2) + (r & 3);
-                    const float o = fmaxf(acc[r] * c3 + b3u, 0.f);
-                    if (valid && row0 + 4 * half + pt < p.N) {
+                    float o = acc[r] * c3 + b3u;
+                    if (p.relu_out) o = fmaxf(o, 0.f);
+                    if (colok && row0 + 4 * half + pt < p.N) {
                         orow[(size_t)pt * p.ldo] = o;
-                        am = max(am, __float_as_uint(o));
+                        if (ocm) ocm[pt] = o;
+                        am = max(am, abs_bits(o));
                     }
                 }
             } else {
@@ -514,10 +534,10 @@ extern "C" int ev2h_sab_timeline_read(long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sab_timeline), sizeof(long long) * 256);
 }
 #endif
-template <int NS>
+template <int C1, int C2, int C3, int NS, int MODE>
 static int launch_fp(SaBP p, hipStream_t st) {
-    using Cfg = SaBCfg<128, 128, 256, NS>;
-    auto k = sa_mlp_max_bf16_kernel<128, 128, 256, NS, false, true>;
+    using Cfg = SaBCfg<C1, C2, C3, NS>;
+    auto k = sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false, MODE>;
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
@@ -526,31 +546,41 @@ static int launch_fp(SaBP p, hipStream_t st) {
     return EV2H_OK;
 }
 
+template <int NS>
+static int dispatch_fp(const SaBP& p, const ev2h_fp_desc* d, hipStream_t st) {
+    if (d->nn_idx && d->C1 == 128 && d->C2 == 128 && d->C3 == 256) return launch_fp<128, 128, 256, NS, 1>(p, st);
+    if (!d->nn_idx && d->C1 == 256 && d->C2 == 256 && d->C3 == 32) return launch_fp<256, 256, 32, NS, 2>(p, st);
+    ev2h_set_error("ev2h_fp_mlp: unsupported chain %d-%d-%d (%s)", d->C1, d->C2, d->C3, d->nn_idx ? "interpolated" : "plain rows");
+    return EV2H_ERR_ARG;
+}
+
 extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
-    EV2H_CHECK_ARG(d && d->T && d->nn_idx && d->nn_w && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
-    EV2H_CHECK_ARG(d->B > 0 && d->N > 0 && d->S >= 3 && d->ldt >= d->C1 && (d->ldt % 4) == 0 && d->ldo >= d->C3);
-    if (d->C1 != 128 || d->C2 != 128 || d->C3 != 256) {
-        ev2h_set_error("ev2h_fp_mlp: unsupported MLP widths %d-%d-%d (128-128-256 only)", d->C1, d->C2, d->C3);
-        return EV2H_ERR_ARG;
-    }
+    EV2H_CHECK_ARG(d && d->T && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
+    EV2H_CHECK_ARG((d->nn_idx != nullptr) == (d->nn_w != nullptr));
+    EV2H_CHECK_ARG(d->B > 0 && d->N > 0 && d->ldt >= d->C1 && (d->ldt % 4) == 0);
+    const int ncols = d->out_cols > 0 ? d->out_cols : d->C3;
+    EV2H_CHECK_ARG(ncols <= d->C3 && d->ldo >= ncols);
+    if (d->nn_idx) EV2H_CHECK_ARG(d->S >= 3);
     SaBP p{};
     p.P1 = d->T; p.ldp = d->ldt; p.nn_idx = d->nn_idx; p.nn_w = d->nn_w; p.N = d->N;
     p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
+    p.ncols = ncols; p.relu_out = d->no_relu_out ? 0 : 1; p.out_cm = d->out_cm;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * p.S, SAB_WAVES);
     if (d->precision == EV2H_PREC_F16X2) {
         p.out_amax = d->out_amax;
-        if (d->t_scale) {
-            EV2H_CHECK_ARG(d->t_amax && d->w2_norm >= 0.f && d->b2_max >= 0.f);
-            // a convex blend of table rows stays inside the table's range (+ rounding): the layer-1 bound is the table's record
+        if (d->t_amax) {
+            EV2H_CHECK_ARG(d->w2_norm >= 0.f && d->b2_max >= 0.f);
+            EV2H_CHECK_ARG(d->nn_idx ? d->t_scale != nullptr : d->t_scale == nullptr);   // tables arrive scaled, plain rows do not
+            // a convex blend of table rows stays inside the table's range (+ rounding): the layer-1 bound is the input's record
             p.p1_scale = d->t_scale; p.p1_amax = d->t_amax; p.w1x_norm = 0.f; p.dmax = 1.f; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
         }
     }
     hipStream_t st = (hipStream_t)stream;
-    if (d->precision == EV2H_PREC_BF16X3) return launch_fp<3>(p, st);
-    if (d->precision == EV2H_PREC_F16X2) return launch_fp<2>(p, st);
-    if (d->precision == EV2H_PREC_BF16) return launch_fp<1>(p, st);
+    if (d->precision == EV2H_PREC_BF16X3) return dispatch_fp<3>(p, d, st);
+    if (d->precision == EV2H_PREC_F16X2) return dispatch_fp<2>(p, d, st);
+    if (d->precision == EV2H_PREC_BF16) return dispatch_fp<1>(p, d, st);
     ev2h_set_error("ev2h_fp_mlp: precision %d is not a 16-bit plane mode (F32: ev2h_three_nn_interp + ev2h_gemm)", d->precision);
     return EV2H_ERR_ARG;
 }

@@ -211,6 +211,36 @@ def feature_propagation(xyz1: torch.Tensor, xyz2: torch.Tensor, points2: torch.T
     return out, idx.long(), w
 
 
+def row_chain(X: torch.Tensor, W2, b2, W3, b3, precision: str = "f16x2", relu_out: bool = False, x_amax=None, out_amax=None):
+    """Two dense layers on plain rows in one kernel (ev2h_fp_mlp form (b); the segmentation head TEHNet.py:135-141 with its BN
+    folded into W3 / b3 by the caller): out = W3 relu(W2 X + b2) + b3.  X [B,N,256], W2 [256,256], W3 [n<=32, 256].
+    x_amax: F16X2 range record [B] of X (None = no range handling).  Returns (out [B,N,n], the same channel-major [B,n,N])."""
+    from .pack import NS_OF, _pad, sa_bf16_images
+    B, N, C1 = X.shape
+    C2, n = W2.shape[0], W3.shape[0]
+    dev = X.device
+    W3p = _pad(W3.detach().cpu().double().numpy(), 32, C2)
+    i2, i3, u2, u3 = sa_bf16_images(W2.detach().cpu().double().numpy(), W3p, NS_OF[precision])
+    b3p = torch.zeros(32, device=dev, dtype=torch.float32)
+    b3p[:n] = b3
+    keep = [torch.from_numpy(i2).to(dev), torch.from_numpy(i3).to(dev), b2.contiguous(), b3p]
+    out = torch.empty(B, N, n, device=dev, dtype=torch.float32)
+    out_cm = torch.empty(B, n, N, device=dev, dtype=torch.float32)
+    Xc = X.contiguous()
+    d = _lib.FpDesc()
+    d.T, d.ldt = Xc.data_ptr(), C1
+    d.b2, d.b3, d.W2s, d.W3s, d.w2_unscale, d.w3_unscale = keep[2].data_ptr(), keep[3].data_ptr(), keep[0].data_ptr(), keep[1].data_ptr(), u2, u3
+    d.out, d.ldo, d.out_cols, d.no_relu_out, d.out_cm = out.data_ptr(), n, n, int(not relu_out), out_cm.data_ptr()
+    d.B, d.N, d.C1, d.C2, d.C3 = B, N, C1, C2, 32
+    d.precision = _lib.PREC[precision]
+    if x_amax is not None:
+        d.t_amax = x_amax.data_ptr()
+        d.w2_norm, d.b2_max = float(W2.abs().sum(1).max()) * (1 + 1e-6), float(b2.abs().max()) * (1 + 1e-6)
+    d.out_amax = _lib.ptr(out_amax)
+    _lib.check(_lib.lib().ev2h_fp_mlp(C.byref(d), _st()), "ev2h_fp_mlp")
+    return out, out_cm
+
+
 def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor, hf_amax: torch.Tensor | None = None):
     """TEHNet.py:13-27 for both hands.  logits_pm [B,N,4], query_pm [2,B,N,256], value_pm [B,N,256]
     -> (sim [B,2,4,256], hf8 [2,B,N,8]).  hf_amax: optional range records [2,B] of the context features."""

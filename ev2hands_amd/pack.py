@@ -203,6 +203,9 @@ class PackedWeights:
         a, be = _bn_affine(sd, "classifier.2")
         self._dense(w.cls0, "cls0", _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be)
         self._dense(w.cls4, "cls4", _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
+        if self.ns:
+            self._cls_module(w.clsm, _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be,
+                             _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
         # query convs: tap-major [O][3*I]; both hands' first conv stacked along O
         W0, b0, a0, be0 = [], [], [], []
         for h, side in enumerate(("left", "right")):
@@ -257,6 +260,24 @@ class PackedWeights:
                 assert W.shape[1] == 515
                 W = np.concatenate([W[:, 3:], W[:, :3], np.zeros((W.shape[0], 5))], 1)
             self._dense(arr[k], f"{prefix}.{k}", W, b)
+
+    def _cls_module(self, br, W0, b0, alpha, beta, W4, b4):
+        """The segmentation head Conv1d -> ReLU -> BN -> (Dropout) -> Conv1d (TEHNet.py:135-141) as a two-layer ev2h_fp_mlp chain:
+        the BN affine y = alpha relu(z) + beta sits between a ReLU and a k=1 convolution, so it folds forward exactly (float64,
+        rounded once): W4' = W4 diag(alpha), b4' = W4 beta + b4.  The 4 output rows are zero-padded to one 32-row tile."""
+        W4f, b4f = W4 * alpha[None, :], W4 @ beta + b4
+        C2, C1 = W0.shape
+        assert (C1, C2) == (256, 256) and W4f.shape[0] <= 32
+        W4p, b4p = _pad(W4f, 32, C2), _pad(b4f, 32)
+        br.b2 = self._dev("clsm.b2", b0)
+        br.b3 = self._dev("clsm.b3", b4p)
+        br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, 32, 32, 0.0
+        br.w1x_norm = 0.0
+        br.w2_norm = float(np.abs(W0).sum(1).max()) * (1 + 1e-6)
+        br.b2_max = float(np.abs(b0).max()) * (1 + 1e-6)
+        i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(W0, W4p, self.ns)
+        br.W2s = self._dev_bytes("clsm.W2s", i2)
+        br.W3s = self._dev_bytes("clsm.W3s", i3)
 
     def _fp_module(self, m, sd, prefix):
         """A three-layer feature-propagation MLP without skip input (fp1, TEHNet.py:129) in the form ev2h_fp_mlp takes: the first

@@ -174,31 +174,40 @@ typedef struct ev2h_sa_desc {
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
-/* ---- fused feature propagation (model/pointnet2_utils.py:296-316 with points1 = None: TEHNet.py:186) --------------
- * out[b][n] = relu(W3' relu(W2' relu(sum_j w[b][n][j] T[b][idx[b][n][j]]) + b2') + b3'),   T = W1' points2 + b1' per coarse point:
- * the first Conv1d commutes with the 3-NN interpolation (a row's weights sum to 1 up to rounding, so carrying b1' inside the
- * table changes a value by <= 2e-7 |b1'|), which makes layer 1 a table over the S coarse points instead of a GEMM over the N
- * fine ones, and layers 2-3 run in registers like ev2h_sa_mlp_max -- the interpolated rows and both hidden layers never
- * reach memory.  nn_idx / nn_w as written by ev2h_three_nn_interp.  16-bit plane precisions only (EV2H_PREC_F32: use
- * ev2h_three_nn_interp + ev2h_gemm); (C1, C2, C3) = (128, 128, 256). */
+/* ---- fused row chains: feature propagation and the segmentation head ---------------------------------------------------
+ * (a) nn_idx != NULL -- PointNetFeaturePropagation with points1 = None (model/pointnet2_utils.py:296-316; fp1 of TEHNet.py:186):
+ *   out[b][n] = relu(W3' relu(W2' relu(sum_j w[b][n][j] T[b][idx[b][n][j]]) + b2') + b3'),   T = W1' points2 + b1' per coarse point:
+ *   the first Conv1d commutes with the 3-NN interpolation (a row's weights sum to 1 up to rounding, so carrying b1' inside the
+ *   table changes a value by <= 2e-7 |b1'|), which makes layer 1 a table over the S coarse points instead of a GEMM over the N
+ *   fine ones, and layers 2-3 run in registers like ev2h_sa_mlp_max -- the interpolated rows and both hidden layers never
+ *   reach memory.  nn_idx / nn_w as written by ev2h_three_nn_interp.  (C1, C2, C3) = (128, 128, 256).
+ * (b) nn_idx == NULL -- two dense layers on plain rows (the classifier, TEHNet.py:135-141,188: Conv1d -> ReLU -> BN -> Conv1d with the
+ *   BN folded FORWARD into the second convolution by the host, exact for a k=1 convolution):
+ *   out[b][n] = W3' relu(W2' T[b][n] + b2') + b3'  (+ ReLU unless no_relu_out),   T [B][N][ldt] = the input rows themselves;
+ *   (C1, C2, C3) = (256, 256, 32) with out_cols <= C3 leading columns written (zero-padded W3' rows), optionally also channel-major.
+ * 16-bit plane precisions only (EV2H_PREC_F32: ev2h_three_nn_interp + ev2h_gemm). */
 typedef struct ev2h_fp_desc {
-    const float* T; int ldt;      /* [B][S][ldt] layer-1 table of the coarse points, C1 columns used (ldt % 4 == 0)     */
-    const int32_t* nn_idx;        /* [B][N][3]                                                                        */
+    const float* T; int ldt;      /* (a) [B][S][ldt] layer-1 table of the coarse points; (b) [B][N][ldt] input rows; C1 columns used */
+    const int32_t* nn_idx;        /* [B][N][3], or NULL: form (b)                                                     */
     const float* nn_w;            /* [B][N][3]                                                                        */
-    const float* b2;              /* [C2]                                                                             */
+    const float* b2;              /* [roundup(C2, 32)]                                                                */
     const float* b3;              /* [C3]                                                                             */
     const void* W2s;              /* tile images as in ev2h_sa_desc                                                   */
     const void* W3s;
     float w2_unscale, w3_unscale;
-    float* out; int ldo;          /* [B][N][ldo], C3 columns written                                                  */
-    int B, N, S;
+    float* out; int ldo;          /* [B][N][ldo], out_cols (0 = C3) columns written                                   */
+    int B, N, S;                  /* S: coarse points per window, form (a)                                            */
     int C1, C2, C3;
     int precision;
-    /* F16X2 range (optional, as in ev2h_sa_desc): the table arrives scaled by the power of two t_scale[b] (ev2h_gemm y_scale) */
-    const float* t_scale;         /* [B]; NULL = unscaled table, no range handling                                    */
-    const uint32_t* t_amax;       /* [B] max |stored T_b|                                                             */
+    /* F16X2 range (optional, as in ev2h_sa_desc).  (a): the table arrives scaled by the power of two t_scale[b] (ev2h_gemm
+     * y_scale) and t_amax is the record of the stored table; (b): t_scale = NULL, t_amax = the record of the input rows. */
+    const float* t_scale;         /* [B]                                                                              */
+    const uint32_t* t_amax;       /* [B]; NULL = no range handling                                                    */
     float w2_norm, b2_max;
     uint32_t* out_amax;           /* [B] range record of `out`, optional                                              */
+    int out_cols;                 /* 0 = C3                                                                           */
+    int no_relu_out;              /* 1: no ReLU after the last layer                                                  */
+    float* out_cm;                /* optional second copy of the output, channel-major [B][out_cols][N]               */
 } ev2h_fp_desc;
 int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
 
@@ -327,6 +336,8 @@ typedef struct ev2h_weights {
     ev2h_sa_module fp1m;                         /* fp1 once more in the form ev2h_fp_mlp takes (16-bit precisions): W1f/b1 = table
                                                     layer, br[0] = layers 2-3 (W1x unused); kf = 128, nbranch = 1               */
     ev2h_dense cls0, cls4;
+    ev2h_sa_branch clsm;                         /* the classifier once more as an ev2h_fp_mlp chain, form (b) (16-bit precisions):
+                                                    W2s = cls0, W3s = cls4 with the BN between them folded in, C3 = 32 (4 used)  */
     ev2h_dense qconv0;                           /* both hands, O = 512, 3 taps                        */
     ev2h_dense qconv4[2];
     ev2h_dense mano_sa2[2][2];

@@ -134,6 +134,33 @@ def test_feature_propagation_fused(kind, B, N1, N2, mag, precision, tol):
         assert torch.equal(ops.range_values(out_amax).cpu(), out.abs().amax(dim=(1, 2)).cpu())
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,N,mag", [(2, 2048, 1.0), (3, 1000, 1.0), (1, 130, 1.0), (2, 512, 1e-5), (2, 512, 3e6)])
+def test_row_chain_segmentation_head(B, N, mag, precision, tol):
+    """ev2h_fp_mlp on plain rows (both classifier layers in one kernel, logits point-major and channel-major) against float64;
+    signed inputs, ragged N, windows of different magnitude, and -- F16X2 -- magnitudes far outside fp16 with range records."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    X = torch.from_numpy(synth.hash_normal("X", (B, N, 256), 21)).float() * mag
+    X[B - 1] *= 0.03
+    W2 = torch.from_numpy(synth.hash_normal("W2", (256, 256), 22) / 16).float()
+    b2 = torch.from_numpy(synth.hash_normal("b2", (256,), 23) * 0.1).float() * mag
+    W3 = torch.from_numpy(synth.hash_normal("W3", (4, 256), 24) / 16).float()
+    b3 = torch.from_numpy(synth.hash_normal("b3", (4,), 25) * 0.1).float() * mag
+    ref = torch.relu(X.double() @ W2.double().T + b2.double()) @ W3.double().T + b3.double()
+    xa = oa = None
+    if precision == "f16x2":
+        xa = ops.range_record(B, "cuda")
+        xa.copy_(X.abs().amax(dim=(1, 2)).view(torch.int32).cuda())
+        oa = ops.range_record(B, "cuda")
+    out, out_cm = ops.row_chain(X.cuda(), W2.cuda(), b2.cuda(), W3.cuda(), b3.cuda(), precision, x_amax=xa, out_amax=oa)
+    for b in range(B):
+        assert rel(out[b], ref[b].float()) < tol, (b, rel(out[b], ref[b].float()))
+    assert torch.equal(out_cm, out.permute(0, 2, 1))
+    if oa is not None:
+        assert torch.equal(ops.range_values(oa).cpu(), out.abs().amax(dim=(1, 2)).cpu())
+
+
 GEMM_CASES = [
     # M,   N,   K,  relu, post, taps, rowmax, group
     (256, 128, 128, True, False, 1, 0, 0),
