@@ -64,7 +64,7 @@ class Weights(C.Structure):
                 ("fp3_skip", Dense), ("fp3_bcast", Dense), ("fp3_1", Dense),
                 ("fp2", Dense * 2), ("fp1", Dense * 3), ("fp1m", SaModule),
                 ("cls0", Dense), ("cls4", Dense), ("clsm", SaBranch),
-                ("qconv0", Dense), ("qconv4", Dense * 2),
+                ("qconv0", Dense), ("qconv4", Dense * 2), ("qconv4T", vp * 2),
                 ("mano_sa2", (Dense * 2) * 2),
                 ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci)]
 
@@ -85,7 +85,7 @@ EXPORTS = [
     "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp",
-    "ev2h_attn_sim", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
+    "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
     "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
 ]
@@ -127,6 +127,9 @@ def lib() -> C.CDLL:
     L.ev2h_fp_mlp.argtypes = [C.POINTER(FpDesc), vp]
     L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
     L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
+    L.ev2h_attn_sim_folded_scratch.restype = C.c_size_t
+    L.ev2h_attn_sim_folded_scratch.argtypes = [ci, ci]
+    L.ev2h_attn_sim_folded.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
     L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp, vp]
     L.ev2h_mano_rotations.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp]
     L.ev2h_forward.argtypes = [C.POINTER(Weights), C.POINTER(ManoConsts), C.POINTER(ManoConsts), vp, ci, ci, ci, ci, vp,

@@ -54,6 +54,101 @@ __global__ __launch_bounds__(1024) void attn_sim_kernel(const float4* __restrict
     }
 }
 
+// ---- the same similarity map with the LAST query convolution folded behind the reduction over the points.
+// query = Conv1d(k=3) -> ReLU -> BN -> Conv1d(k=3) -> BN (TEHNet.py:150-166) enters the attention only through
+// sum_n key[c][n] query[d][n], and its last Conv1d -> BN is affine:  query[d][n] = sum_t sum_i W[d][t][i] q1[i][n + t - 1] + b[d]
+// (q1 = output of the first conv block, zero padded), hence
+//     sum_n key[c][n] query[d][n] = sum_t sum_i W[d][t][i] Z[c][t][i] + b[d] K[c],
+//     Z[c][t][i] = sum_n key[c][n] q1[i][n + t - 1],      K[c] = sum_n key[c][n]:
+// a [4 x 768] x [768 x 256] product per (window, hand) instead of an [N x 768] x [768 x 256] convolution -- 206 GMAC per
+// 256-window batch (both hands) become one streaming pass over q1 and 0.4 GMAC.  Everything in fp32 fma chains with a fixed
+// summation order (chunk partials are summed in chunk order: no atomics, results are reproducible and batch-independent).
+constexpr int ZS_ROWS = 256;      // points per partial sum
+
+// grid (chunks, B): thread j owns columns 2j, 2j+1 of the 512-wide q1 rows (both hands side by side) and their 12 (class, tap) sums
+__global__ __launch_bounds__(256) void attn_zsum_kernel(const float4* __restrict__ logits, const float* __restrict__ q1, int ldq, int N,
+                                                        float* __restrict__ zpart) {
+    __shared__ float4 sk[ZS_ROWS + 2];        // key rows n0 - 1 .. n0 + ZS_ROWS (zero outside the window)
+    const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x, tid = threadIdx.x;
+    const int n0 = ch * ZS_ROWS, n1 = min(N, n0 + ZS_ROWS);
+    for (int i = tid; i < ZS_ROWS + 2; i += 256) {
+        const int n = n0 - 1 + i;
+        sk[i] = (n >= 0 && n < N) ? logits[(size_t)b * N + n] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float ax[3][4], ay[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { ax[t][c] = 0.f; ay[t][c] = 0.f; }
+    const float* qp = q1 + ((size_t)b * N + n0) * ldq + 2 * tid;
+    auto step = [&](int i, float2 v) {        // row n0 + i: tap t pairs it with key[n0 + i - t + 1] = sk[i + 2 - t]
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float4 k = sk[i + 2 - t];
+            ax[t][0] = fmaf(k.x, v.x, ax[t][0]); ax[t][1] = fmaf(k.y, v.x, ax[t][1]); ax[t][2] = fmaf(k.z, v.x, ax[t][2]); ax[t][3] = fmaf(k.w, v.x, ax[t][3]);
+            ay[t][0] = fmaf(k.x, v.y, ay[t][0]); ay[t][1] = fmaf(k.y, v.y, ay[t][1]); ay[t][2] = fmaf(k.z, v.y, ay[t][2]); ay[t][3] = fmaf(k.w, v.y, ay[t][3]);
+        }
+    };
+    const int rows = n1 - n0;
+    int i = 0;
+    for (; i + 4 <= rows; i += 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(qp + (size_t)(i + u) * ldq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) step(i + u, v[u]);
+    }
+    for (; i < rows; ++i) step(i, *reinterpret_cast<const float2*>(qp + (size_t)i * ldq));
+    float* zp = zpart + ((size_t)b * nch + ch) * 12 * 512 + 2 * tid;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<float2*>(zp + (c * 3 + t) * 512) = make_float2(ax[t][c], ay[t][c]);
+}
+
+// grid (B, 2): thread d finishes column d of the hand's similarity map
+__global__ __launch_bounds__(256) void attn_simfold_kernel(const float* __restrict__ zpart, int nch, const float4* __restrict__ logits, int N,
+                                                           const float* __restrict__ w4t0, const float* __restrict__ w4t1,
+                                                           const float* __restrict__ b40, const float* __restrict__ b41, float* __restrict__ sim) {
+    __shared__ float4 zs[3 * ATT_D];          // zs[t * 256 + i] = Z[0..3][t][i]
+    __shared__ float4 kp[256];
+    const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    const float* w4t = h ? w4t1 : w4t0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int ch = 0; ch < nch; ++ch)      // fixed order
+#pragma unroll
+            for (int c = 0; c < 4; ++c) z[c] += zpart[(((size_t)b * nch + ch) * 12 + c * 3 + t) * 512 + h * ATT_D + d];
+        zs[t * ATT_D + d] = make_float4(z[0], z[1], z[2], z[3]);
+    }
+    float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = d; n < N; n += 256) {
+        const float4 k = logits[(size_t)b * N + n];
+        ks.x += k.x; ks.y += k.y; ks.z += k.z; ks.w += k.w;
+    }
+    kp[d] = ks;
+    __syncthreads();
+    float4 K = kp[0];
+    for (int j = 1; j < 256; ++j) { const float4 k = kp[j]; K.x += k.x; K.y += k.y; K.z += k.z; K.w += k.w; }
+    const float bd = (h ? b41 : b40)[d];
+    float a0 = bd * K.x, a1 = bd * K.y, a2 = bd * K.z, a3 = bd * K.w;
+#pragma unroll 8
+    for (int k = 0; k < 3 * ATT_D; ++k) {
+        const float w = w4t[(size_t)k * ATT_D + d];
+        const float4 z = zs[k];
+        a0 = fmaf(w, z.x, a0); a1 = fmaf(w, z.y, a1); a2 = fmaf(w, z.z, a2); a3 = fmaf(w, z.w, a3);
+    }
+    const float s[4] = {0.0625f * a0, 0.0625f * a1, 0.0625f * a2, 0.0625f * a3};     // (value channels = 256) ** -0.5, TEHNet.py:22
+    const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+    float e[4], sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { e[c] = expf(s[c] - mx); sum += e[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sim[(((size_t)b * 2 + h) * 4 + c) * ATT_D + d] = e[c] / sum;
+}
+
 // one wave per point: lanes hold 4 channels each of the 256-wide value row, both hands' sim in registers
 constexpr int CTX_PTS_PER_WAVE = 32;
 __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restrict__ sim, const float* __restrict__ value,
@@ -116,6 +211,25 @@ extern "C" int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int 
     EV2H_CHECK_ARG(logits_pm && query_pm && sim && B > 0 && N > 0 && ldq >= ATT_D);
     dim3 grid(B, 2);
     attn_sim_kernel<<<grid, 1024, 0, (hipStream_t)stream>>>((const float4*)logits_pm, query_pm, ldq, query_hand_stride, N, sim);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+extern "C" size_t ev2h_attn_sim_folded_scratch(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * ceil_div(N, ZS_ROWS) * 12 * 512;
+}
+
+extern "C" int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, int ldq, int B, int N, const float* w4t_left,
+                                    const float* w4t_right, const float* b4_left, const float* b4_right, float* scratch, float* sim,
+                                    ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(logits_pm && q1_pm && w4t_left && w4t_right && b4_left && b4_right && scratch && sim);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && ldq >= 2 * ATT_D && (ldq % 2) == 0);
+    const int nch = ceil_div(N, ZS_ROWS);
+    attn_zsum_kernel<<<dim3(nch, B), 256, 0, (hipStream_t)stream>>>((const float4*)logits_pm, q1_pm, ldq, N, scratch);
+    EV2H_CHECK_LAUNCH();
+    attn_simfold_kernel<<<dim3(B, 2), 256, 0, (hipStream_t)stream>>>(scratch, nch, (const float4*)logits_pm, N, w4t_left, w4t_right, b4_left,
+                                                                      b4_right, sim);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -197,6 +197,7 @@ static void build_layout(Layout& L, int B, int N) {
     L.add("logits_pm", R * 4);
     L.add("q1", R * 512);
     L.add("q2", 2 * R * 256);
+    L.add("zpart", ev2h_attn_sim_folded_scratch(B, N));
     L.add("sim", b * 2 * 4 * 256);
     L.add("hf8", 2 * R * 8);
     L.add("nn2_idx", b * 512 * 3);
@@ -498,11 +499,20 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N, R_Q1, N), nullptr, 0, 0, 3, N));
-    for (int h = 0; h < 2; ++h)
-        RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
-    // ---- attention (TEHNet.py:13-27)
+    // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
+    // over the points (ev2h_attn_sim_folded): q2 is never formed
+    static const bool unfolded = getenv("EV2H_ATTN_UNFOLDED") != nullptr;        // A/B switch: the two k=3 GEMMs + ev2h_attn_sim
+    if (unfolded) {
+        for (int h = 0; h < 2; ++h)
+            RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
+    }
     if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));              // logits ready
-    RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
+    if (unfolded) {
+        RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
+    } else {
+        RUN(ev2h_attn_sim_folded(ws.f("logits_pm"), ws.f("q1"), 512, B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
+                                 ws.f("zpart"), ws.f("sim"), st));
+    }
     RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
     if (fork) {

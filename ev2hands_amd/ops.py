@@ -253,6 +253,23 @@ def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.T
     return sim, hf8
 
 
+def attention_sim_folded(logits_pm: torch.Tensor, q1_pm: torch.Tensor, W4, b4) -> torch.Tensor:
+    """sim [B,2,4,256] of TEHNet.py:20-22 from the FIRST query block's output: the last Conv1d(k=3) -> BN of each hand is folded
+    behind the sum over the points (ev2h_attn_sim_folded).  logits_pm [B,N,4], q1_pm [B,N,512] (hand h at columns h*256..),
+    W4 = (left, right) folded weights [256, 768] tap-major, b4 = (left, right) [256]."""
+    B, N, _ = logits_pm.shape
+    dev = logits_pm.device
+    L = _lib.lib()
+    wt = [w.t().contiguous() for w in W4]
+    bb = [b.contiguous() for b in b4]
+    scratch = torch.empty(L.ev2h_attn_sim_folded_scratch(B, N), device=dev, dtype=torch.float32)
+    sim = torch.empty(B, 2, 4, 256, device=dev, dtype=torch.float32)
+    lg, q1 = logits_pm.contiguous(), q1_pm.contiguous()
+    _lib.check(L.ev2h_attn_sim_folded(lg.data_ptr(), q1.data_ptr(), 512, B, N, wt[0].data_ptr(), wt[1].data_ptr(), bb[0].data_ptr(),
+                                      bb[1].data_ptr(), scratch.data_ptr(), sim.data_ptr(), _st()), "ev2h_attn_sim_folded")
+    return sim
+
+
 def mano_rotations(theta: torch.Tensor) -> torch.Tensor:
     """Axis-angle vectors [M,16,3] -> the rotation matrices [M,16,3,3] the MANO kernel computes for them (ev2h_mano_rotations with
     an identity pose basis and a zero mean pose, so that the full pose IS theta).  Parity hook for losses.py:14-51."""

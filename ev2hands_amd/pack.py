@@ -219,6 +219,7 @@ class PackedWeights:
             W4, b4 = _fold(sd, p + ".4", p + ".5")
             W4 = np.ascontiguousarray(W4.transpose(0, 2, 1)).reshape(W4.shape[0], -1)
             self._dense(w.qconv4[h], p + ".4", W4, b4, K=256)
+            w.qconv4T[h] = self._dev(p + ".4.WT", np.ascontiguousarray(W4.T))        # [768, 256]: ev2h_attn_sim_folded
         self._dense(w.qconv0, "qconv0", np.concatenate(W0, 0), np.concatenate(b0), np.concatenate(a0),
                     np.concatenate(be0), K=256)
 

@@ -216,6 +216,20 @@ int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
  * is query_pm + h*256 with row stride ldq.  logits_pm [B*N][4]; sim [B][2][4][256]. */
 int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int ldq, size_t query_hand_stride, int B, int N, float* sim,
                   ev2h_stream_t stream);
+/* The same sim with the LAST query convolution folded behind the sum over the points.  query = Conv1d(k=3) -> ReLU -> BN ->
+ * Conv1d(k=3) -> BN (TEHNet.py:150-166) enters the attention only through sum_n key[c][n] query[d][n] (TEHNet.py:20), and its last
+ * Conv1d -> BN is affine in q1 (the first block's output): with W, b the BN-folded second convolution,
+ *     sum_n key[c][n] query[d][n] = sum_t sum_i W[d][t][i] Z[c][t][i] + b[d] K[c],
+ *     Z[c][t][i] = sum_n key[c][n] q1[i][n + t - 1] (zero padded),   K[c] = sum_n key[c][n]
+ * -- one streaming pass over q1 and a [4 x 768] x [768 x 256] product per (window, hand) instead of an [N x 768] x [768 x 256]
+ * convolution per hand; exact fp32 fma chains in a fixed order (no atomics).  A re-association of the reference's sum: results
+ * agree to fp32 rounding, not bit for bit.
+ * q1_pm [B*N][ldq]: hand h's 256 channels at column h*256.  w4t_* [768][256] = W transposed (row t*256 + i, column d), b4_* [256].
+ * scratch: ev2h_attn_sim_folded_scratch(B, N) floats. */
+size_t ev2h_attn_sim_folded_scratch(int B, int N);
+int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, int ldq, int B, int N, const float* w4t_left,
+                         const float* w4t_right, const float* b4_left, const float* b4_right, float* scratch, float* sim,
+                         ev2h_stream_t stream);
 /* hf8[h][b*N + n][0..3] = sum_d sim[b][h][c][d] * value[b*N+n][d]; columns 4..7 are written as 0. */
 int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax,
                       int amax_hand_stride, ev2h_stream_t stream);
@@ -340,6 +354,7 @@ typedef struct ev2h_weights {
                                                     W2s = cls0, W3s = cls4 with the BN between them folded in, C3 = 32 (4 used)  */
     ev2h_dense qconv0;                           /* both hands, O = 512, 3 taps                        */
     ev2h_dense qconv4[2];
+    const float* qconv4T[2];                     /* the same folded weights transposed, [768][256] (ev2h_attn_sim_folded)      */
     ev2h_dense mano_sa2[2][2];
     ev2h_dense head0[2], head4[2];
     int precision;                               /* EV2H_PREC_* used by the MFMA kernels               */

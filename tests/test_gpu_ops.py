@@ -349,6 +349,43 @@ def test_attention():
         assert float(hf8[h, :, :, 4:].abs().max()) == 0.0
 
 
+# the softmax arguments here are sums of N products of O(1) numbers (|s| up to ~10): an fp32 sum of 2048 terms carries ~1e-6 of
+# absolute error, which the exponential turns into the same RELATIVE error of the map -- for either order of summation
+TOL_SIM = 5e-6
+
+
+@pytest.mark.parametrize("B,N", [(2, 2048), (3, 1000), (1, 130), (2, 257)])
+def test_attention_sim_folded(B, N):
+    """ev2h_attn_sim_folded (the last query Conv1d(k=3) -> BN folded behind the attention's sum over the points) against the
+    reference's order of operations in float64: zero-padded F.conv1d over the points, bmm with the key, scale, softmax over the
+    classes (TEHNet.py:13-22,155-156).  N not a multiple of the 256-point partial sums; a bias, so the sum-of-keys term matters."""
+    _need_gpu()
+    import torch.nn.functional as F
+    from ev2hands_amd import ops
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, 19) * sc).float()                   # noqa: E731
+    key = g("k", (B, 4, N))
+    q1 = g("q1", (B, 512, N))                                  # both hands' first-block outputs (signed: post-ReLU BN shifts them)
+    W = [g(f"W{h}", (256, 256, 3), 0.05) for h in range(2)]    # [O, I, tap]
+    bias = [g(f"b{h}", (256,), 0.2) for h in range(2)]
+    ref = []
+    for h in range(2):
+        q2 = F.conv1d(q1[:, h * 256:(h + 1) * 256].double(), W[h].double(), bias[h].double(), padding=1)          # [B,256,N]
+        ref.append(torch.softmax(torch.bmm(key.double(), q2.permute(0, 2, 1)) * 256 ** -0.5, dim=1))             # [B,4,256]
+    Wt = [W[h].permute(0, 2, 1).reshape(256, 768).contiguous().cuda() for h in range(2)]                         # tap-major
+    sim = ops.attention_sim_folded(key.permute(0, 2, 1).contiguous().cuda(), q1.permute(0, 2, 1).contiguous().cuda(), Wt,
+                                   [b.cuda() for b in bias])
+    errs = [rel(sim[:, h], ref[h].float()) for h in range(2)]
+    print(f"folded sim B={B} N={N}: rel err {errs[0]:.2e} {errs[1]:.2e}")
+    for h in range(2):
+        assert errs[h] < TOL_SIM, errs[h]
+    # and next to the unfolded kernels of this library on the same inputs (k=3 GEMM in exact fp32, then ev2h_attn_sim)
+    q2g = torch.stack([ops.dense(q1.permute(0, 2, 1).reshape(B * N, 512)[:, h * 256:(h + 1) * 256].contiguous().cuda(), Wt[h], bias[h].cuda(),
+                                 taps=3, rows_per_seq=N, K=256).view(B, N, 256) for h in range(2)])
+    sim2, _ = ops.attention(key.permute(0, 2, 1).contiguous().cuda(), q2g.contiguous(), torch.zeros(B, N, 256, device="cuda"))
+    print(f"   unfolded kernels vs float64: {rel(sim2[:, 0], ref[0].float()):.2e}; folded vs unfolded: {rel(sim, sim2):.2e}")
+    assert rel(sim2[:, 0], ref[0].float()) < TOL_SIM and rel(sim, sim2) < 2 * TOL_SIM
+
+
 @pytest.mark.parametrize("side", ["left", "right"])
 def test_mano_layer(side):
     _need_gpu()
