@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ("post_scale", vp), ("post_shift", vp),
                 ("taps", ci), ("rows_per_seq", ci), ("rowmax_rows", ci), ("precision", ci), ("Ws", vp), ("ws_tile_rows", ci), ("w_unscale", C.c_float),
                 ("x_amax", vp), ("x_amax2", vp), ("x_group_rows", ci), ("y_amax", vp), ("y_group_rows", ci), ("y_scale", vp),
-                ("y_bound_w", C.c_float), ("y_bound_b", C.c_float)]
+                ("y_bound_w", C.c_float), ("y_bound_b", C.c_float), ("skinny", ci)]
 
 
 class SaDesc(C.Structure):

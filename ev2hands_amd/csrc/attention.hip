@@ -107,46 +107,65 @@ __global__ __launch_bounds__(256) void attn_zsum_kernel(const float4* __restrict
         for (int t = 0; t < 3; ++t) *reinterpret_cast<float2*>(zp + (c * 3 + t) * 512) = make_float2(ax[t][c], ay[t][c]);
 }
 
-// grid (B, 2): thread d finishes column d of the hand's similarity map
-__global__ __launch_bounds__(256) void attn_simfold_kernel(const float* __restrict__ zpart, int nch, const float4* __restrict__ logits, int N,
-                                                           const float* __restrict__ w4t0, const float* __restrict__ w4t1,
-                                                           const float* __restrict__ b40, const float* __restrict__ b41, float* __restrict__ sim) {
+// grid (B, 2), 1024 threads: thread (q, d) sums the q-th quarter of the 768 contraction steps of column d; the four partial sums
+// are added in quarter order
+__global__ __launch_bounds__(1024) void attn_simfold_kernel(const float* __restrict__ zpart, int nch, const float4* __restrict__ logits, int N,
+                                                            const float* __restrict__ w4t0, const float* __restrict__ w4t1,
+                                                            const float* __restrict__ b40, const float* __restrict__ b41, float* __restrict__ sim) {
     __shared__ float4 zs[3 * ATT_D];          // zs[t * 256 + i] = Z[0..3][t][i]
-    __shared__ float4 kp[256];
-    const int b = blockIdx.x, h = blockIdx.y, d = threadIdx.x;
+    __shared__ float4 kp[1024];
+    __shared__ float4 kp2[32];
+    __shared__ float red[3][4][ATT_D];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, d = tid & (ATT_D - 1), q = tid >> 8;
     const float* w4t = h ? w4t1 : w4t0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
+    if (q < 3) {                              // chunk partials of tap q, in chunk order
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < nch; ++ch)      // fixed order
+        for (int ch = 0; ch < nch; ++ch)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) z[c] += zpart[(((size_t)b * nch + ch) * 12 + c * 3 + t) * 512 + h * ATT_D + d];
-        zs[t * ATT_D + d] = make_float4(z[0], z[1], z[2], z[3]);
+            for (int c = 0; c < 4; ++c) z[c] += zpart[(((size_t)b * nch + ch) * 12 + c * 3 + q) * 512 + h * ATT_D + d];
+        zs[q * ATT_D + d] = make_float4(z[0], z[1], z[2], z[3]);
     }
     float4 ks = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = d; n < N; n += 256) {
+    for (int n = tid; n < N; n += 1024) {
         const float4 k = logits[(size_t)b * N + n];
         ks.x += k.x; ks.y += k.y; ks.z += k.z; ks.w += k.w;
     }
-    kp[d] = ks;
+    kp[tid] = ks;
     __syncthreads();
-    float4 K = kp[0];
-    for (int j = 1; j < 256; ++j) { const float4 k = kp[j]; K.x += k.x; K.y += k.y; K.z += k.z; K.w += k.w; }
-    const float bd = (h ? b41 : b40)[d];
-    float a0 = bd * K.x, a1 = bd * K.y, a2 = bd * K.z, a3 = bd * K.w;
+    if (tid < 32) {
+        float4 k2 = kp[tid * 32];
+        for (int j = 1; j < 32; ++j) { const float4 k = kp[tid * 32 + j]; k2.x += k.x; k2.y += k.y; k2.z += k.z; k2.w += k.w; }
+        kp2[tid] = k2;
+    }
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (q == 0) {
+        float4 K = kp2[0];
+        for (int j = 1; j < 32; ++j) { const float4 k = kp2[j]; K.x += k.x; K.y += k.y; K.z += k.z; K.w += k.w; }
+        const float bd = (h ? b41 : b40)[d];
+        a0 = bd * K.x; a1 = bd * K.y; a2 = bd * K.z; a3 = bd * K.w;
+    }
+    constexpr int KQ = 3 * ATT_D / 4;
 #pragma unroll 8
-    for (int k = 0; k < 3 * ATT_D; ++k) {
+    for (int k = q * KQ; k < (q + 1) * KQ; ++k) {
         const float w = w4t[(size_t)k * ATT_D + d];
         const float4 z = zs[k];
         a0 = fmaf(w, z.x, a0); a1 = fmaf(w, z.y, a1); a2 = fmaf(w, z.z, a2); a3 = fmaf(w, z.w, a3);
     }
-    const float s[4] = {0.0625f * a0, 0.0625f * a1, 0.0625f * a2, 0.0625f * a3};     // (value channels = 256) ** -0.5, TEHNet.py:22
-    const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-    float e[4], sum = 0.f;
+    if (q > 0) { red[q - 1][0][d] = a0; red[q - 1][1][d] = a1; red[q - 1][2][d] = a2; red[q - 1][3][d] = a3; }
+    __syncthreads();
+    if (q == 0) {
+        const float t[4] = {a0, a1, a2, a3};
+        float s[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { e[c] = expf(s[c] - mx); sum += e[c]; }
+        for (int c = 0; c < 4; ++c) s[c] = 0.0625f * (((t[c] + red[0][c][d]) + red[1][c][d]) + red[2][c][d]);    // 256 ** -0.5, TEHNet.py:22
+        const float mx = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        float e[4], sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sim[(((size_t)b * 2 + h) * 4 + c) * ATT_D + d] = e[c] / sum;
+        for (int c = 0; c < 4; ++c) { e[c] = expf(s[c] - mx); sum += e[c]; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sim[(((size_t)b * 2 + h) * 4 + c) * ATT_D + d] = e[c] / sum;
+    }
 }
 
 // one wave per point: lanes hold 4 channels each of the 256-wide value row, both hands' sim in registers
@@ -228,7 +247,7 @@ extern "C" int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, 
     const int nch = ceil_div(N, ZS_ROWS);
     attn_zsum_kernel<<<dim3(nch, B), 256, 0, (hipStream_t)stream>>>((const float4*)logits_pm, q1_pm, ldq, N, scratch);
     EV2H_CHECK_LAUNCH();
-    attn_simfold_kernel<<<dim3(B, 2), 256, 0, (hipStream_t)stream>>>(scratch, nch, (const float4*)logits_pm, N, w4t_left, w4t_right, b4_left,
+    attn_simfold_kernel<<<dim3(B, 2), 1024, 0, (hipStream_t)stream>>>(scratch, nch, (const float4*)logits_pm, N, w4t_left, w4t_right, b4_left,
                                                                       b4_right, sim);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

@@ -247,8 +247,9 @@ static thread_local int g_precision = EV2H_PREC_F32;   // set by ev2h_forward fo
 
 static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st, const Rng& rg,
                  const float* group_bias = nullptr, int group_rows = 0, int ldbias = 0, int taps = 1, int rows_per_seq = 0,
-                 int rowmax_rows = 0) {
+                 int rowmax_rows = 0, int skinny = 0) {
     ev2h_gemm_desc d{};
+    d.skinny = skinny;
     d.x_amax = rg.xa; d.x_amax2 = rg.xa2; d.x_group_rows = rg.xg; d.y_amax = rg.ya; d.y_group_rows = rg.yg;
     d.X = X; d.ldx = ldx; d.W = w.W; d.ldw = w.ldw; d.Y = Y; d.ldy = ldy;
     d.M = M; d.N = w.O; d.K = w.K;
@@ -438,7 +439,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->sa3[1], ws.f("sa3h1"), 256, B * 128, ws.f("sa3h2"), 512, 1, st, rg(R_SA3H1, 128, R_SA3H2, 128)));
     RUN(dense(w->sa3[2], ws.f("sa3h2"), 512, B * 128, ws.f("l3"), 1024, 1, st, rg(R_SA3H2, 128, R_L3, 1), nullptr, 0, 0, 1, 0, 128));
     // ---- fp3 (TEHNet.py:184): the single l3 point is broadcast, so its 1024 inputs collapse to a per-window bias
-    RUN(dense(w->fp3_bcast, ws.f("l3"), 1024, B, ws.f("fp3bias"), 256, 0, st, rg(R_L3, 1)));
+    RUN(dense(w->fp3_bcast, ws.f("l3"), 1024, B, ws.f("fp3bias"), 256, 0, st, rg(R_L3, 1), nullptr, 0, 0, 1, 0, 0, 1));
     RUN(dense(w->fp3_skip, ws.f("l2buf"), 520, B * 128, ws.f("fp3h"), 256, 1, st, rg(R_L2, 128, R_FP3H, 128, R_FEAT), ws.f("fp3bias"), 128, 256));
     RUN(dense(w->fp3_1, ws.f("fp3h"), 256, B * 128, ws.f("fp3o"), 256, 1, st, rg(R_FP3H, 128, R_FP3O, 128)));
     // ---- fp2 (TEHNet.py:185): 3-NN 128 -> 512, concat [skip 320 | interpolated 256]
@@ -532,8 +533,8 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         EV2H_CHECK_LAUNCH();
         RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh, rg(R_M1 + h, 128, R_MSA2H + h, 128, R_FEAT)));
         RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, rg(R_MSA2H + h, 128, R_M2 + h, 1), nullptr, 0, 0, 1, 0, 128));
-        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh, rg(R_M2 + h, 1, R_FC1 + h, 1)));
-        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh, rg(R_FC1 + h, 1)));
+        RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh, rg(R_M2 + h, 1, R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
+        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh, rg(R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
         if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
     }
     return EV2H_OK;

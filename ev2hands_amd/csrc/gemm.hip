@@ -281,6 +281,75 @@ __global__ __launch_bounds__(256) void transpose_logits_kernel(const float4* __r
     o[0] = v.x; o[(size_t)N] = v.y; o[(size_t)2 * N] = v.z; o[(size_t)3 * N] = v.w;
 }
 
+// ---------------------------------------------------------------------------------------- one row per window
+// The layers whose M is the number of WINDOWS (the broadcast half of fp3, the two Linear layers of each MANO head: M = B, K = 512 or
+// 1024) leave a 128 x 128-tile kernel with 2-16 workgroups walking a 16-32 step K loop: 55-70 us each, on the critical path, and
+// the same at B = 1.  Here the parallelism comes from K (see the kernel); the summation order is fixed and batch-independent, and
+// the arithmetic is exact fp32 fma chains in every precision mode, so no operand planes and no range scaling are involved.
+// Chosen by the caller (ev2h_gemm_desc.skinny), never by M: a window's result must not depend on the batch size.
+struct SkinnyP {
+    const float* X; int ldx;
+    const float* W; int ldw;
+    float* Y; int ldy;
+    int M, N, K;
+    const float* bias; int relu;
+    const float* post_scale; const float* post_shift;
+    unsigned* y_amax; int y_group_rows;
+};
+
+// A wave owns 8 rows x 8 columns and its 64 lanes split K (lane l takes k = 4l .. 4l+3 of every 256-wide step: every load is a
+// coalesced 1 KiB row segment); the 64 lane-partial sums of each output are then combined by a halving butterfly (6 steps, 63
+// shuffle+adds, fixed order) that leaves output q = 8 i + j in lane q.
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyP p) {
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int r0 = blockIdx.y * 8, c0 = (blockIdx.x * 4 + wave) * 8;
+    if (c0 >= p.N) return;                                   // wave-uniform
+    const float* xr[8]; const float* wr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xr[i] = p.X + (size_t)min(r0 + i, p.M - 1) * p.ldx;
+        wr[i] = p.W + (size_t)min(c0 + i, p.N - 1) * p.ldw;
+    }
+    float v[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) v[q] = 0.f;
+    for (int k = 4 * l; k < p.K; k += 256) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a[i] = *reinterpret_cast<const float4*>(xr[i] + k); b[i] = *reinterpret_cast<const float4*>(wr[i] + k); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[8 * i + j] = fmaf(a[i].w, b[j].w, fmaf(a[i].z, b[j].z, fmaf(a[i].y, b[j].y, fmaf(a[i].x, b[j].x, v[8 * i + j]))));
+    }
+    // halving butterfly: at the step of lane bit m a lane keeps the half of its values selected by that bit and receives the
+    // partner's copy of the same half
+#define SKINNY_STEP(M_, N_)                                                                       \
+    {                                                                                             \
+        const bool hi = l & (M_);                                                                 \
+        _Pragma("unroll") for (int q = 0; q < (N_) / 2; ++q)                                      \
+            v[q] = (hi ? v[q + (N_) / 2] : v[q]) + __shfl_xor(hi ? v[q] : v[q + (N_) / 2], (M_), 64); \
+    }
+    SKINNY_STEP(32, 64) SKINNY_STEP(16, 32) SKINNY_STEP(8, 16) SKINNY_STEP(4, 8) SKINNY_STEP(2, 4) SKINNY_STEP(1, 2)
+#undef SKINNY_STEP
+    const int row = r0 + (l >> 3), col = c0 + (l & 7);
+    float o = v[0];
+    const bool ok = row < p.M && col < p.N;
+    if (col < p.N) {
+        if (p.bias) o += p.bias[col];
+        if (p.relu) o = fmaxf(o, 0.f);
+        if (p.post_scale) o = fmaf(o, p.post_scale[col], p.post_shift[col]);
+    }
+    if (ok) p.Y[(size_t)row * p.ldy + col] = o;
+    if (p.y_amax) {                          // F16X2 range record of the output: one atomic per row and wave
+        unsigned ab = ok ? (__float_as_uint(o) & 0x7fffffffu) : 0u;
+#pragma unroll
+        for (int s = 4; s >= 1; s >>= 1) ab = max(ab, (unsigned)__shfl_xor((int)ab, s, 64));
+        if ((l & 7) == 0 && row < p.M && ab) atomicMax(&p.y_amax[row / p.y_group_rows], ab);
+    }
+}
+
 }  // namespace
 
 int ev2h_gemm_init() {       // per device (ev2h_init)
@@ -325,6 +394,17 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
             t.y_amax = d->y_amax; t.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
         }
         table_k8_kernel<<<ceil_div(d->M, TB_WAVES * TB_ROWS_PER_WAVE), 256, 0, (hipStream_t)stream>>>(t);
+        EV2H_CHECK_LAUNCH();
+        return EV2H_OK;
+    }
+    static const bool no_skinny = getenv("EV2H_NO_SKINNY_KERNEL") != nullptr;      // A/B switch
+    if (d->skinny && !no_skinny) {
+        EV2H_CHECK_ARG(d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->y_scale);
+        SkinnyP q{};
+        q.X = d->X; q.ldx = d->ldx; q.W = d->W; q.ldw = d->ldw; q.Y = d->Y; q.ldy = d->ldy; q.M = d->M; q.N = d->N; q.K = d->K;
+        q.bias = d->bias; q.relu = d->relu; q.post_scale = d->post_scale; q.post_shift = d->post_shift;
+        if (d->precision == EV2H_PREC_F16X2 && d->y_amax) { q.y_amax = d->y_amax; q.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1; }
+        gemm_skinny_kernel<<<dim3(ceil_div(d->N, 32), ceil_div(d->M, 8)), 256, 0, (hipStream_t)stream>>>(q);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;
     }

@@ -88,7 +88,8 @@ def three_nn_interpolate(xyz1: torch.Tensor, xyz2: torch.Tensor, feat2: torch.Te
 
 def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=None, post_shift=None, taps=1,
           rows_per_seq=0, rowmax_rows=0, bias_group_rows=0, K=None, precision: str = "f32", presplit: bool = True, w_image=None, w_tile_rows: int = 128,
-          x_amax=None, x_amax2=None, x_group_rows=0, y_amax=None, y_group_rows=0, y_scale=None, y_bound_w=0.0, y_bound_b=0.0) -> torch.Tensor:
+          x_amax=None, x_amax2=None, x_group_rows=0, y_amax=None, y_group_rows=0, y_scale=None, y_bound_w=0.0, y_bound_b=0.0,
+          skinny: bool = False) -> torch.Tensor:
     """Y = post(relu(X W^T + b)); X [M,ldx], W [N,ldw] (ev2h_gemm).  K defaults to X.shape[1].
     x_amax .. y_bound_b: the F16X2 range arguments of ev2h_gemm_desc (range_record tensors)."""
     M, ldx = X.shape
@@ -109,6 +110,7 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False, post_scale=No
     d.x_amax, d.x_amax2, d.x_group_rows = _lib.ptr(x_amax), _lib.ptr(x_amax2), x_group_rows
     d.y_amax, d.y_group_rows = _lib.ptr(y_amax), y_group_rows
     d.y_scale, d.y_bound_w, d.y_bound_b = _lib.ptr(y_scale), y_bound_w, y_bound_b
+    d.skinny = int(skinny)
     keep = None
     d.ws_tile_rows = w_tile_rows
     if w_image is not None:

@@ -127,6 +127,10 @@ typedef struct ev2h_gemm_desc {
     float y_bound_w, y_bound_b;  /* stored times the power of two s[g] with (y_bound_w * max|X_g| + y_bound_b) * s[g] in          */
                                  /* [2^14, 2^15) -- y_bound_w >= max row L1 norm of W makes that a bound of |Y| (+ whatever the   */
                                  /* caller adds to y_bound_b); used for the layer-1 tables of ev2h_sa_mlp_max                     */
+    int skinny;                  /* 1: the layer has ONE ROW PER WINDOW (M = B: fp3's broadcast half, the Linear layers of the MANO heads,
+                                    TEHNet.py:49-55, pointnet2_utils.py:293-294): a kernel that parallelises over K instead of over rows, exact
+                                    fp32 fma chains in every precision (x_amax is not needed, y_amax is still maintained).  Needs taps == 1,
+                                    no rowmax / per-group bias / y_scale.  The caller sets it by layer, never by batch size.     */
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 

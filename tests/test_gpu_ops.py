@@ -214,6 +214,36 @@ def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
     assert err < tol
 
 
+@pytest.mark.parametrize("M,N,K,relu,post", [(256, 1024, 512, True, True), (5, 22, 1024, False, False), (1, 256, 1024, False, False),
+                                              (37, 70, 48, True, False), (2048, 22, 1024, False, False)])
+def test_gemm_skinny_rows_are_windows(M, N, K, relu, post):
+    """The one-row-per-window layers (ev2h_gemm_desc.skinny): exact fp32 whatever the precision mode (bit-identical across modes),
+    a row's result independent of how many rows the call has, range record of the output maintained."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    X = torch.from_numpy(synth.hash_normal("X", (M, K), 52)).float() * 3e5          # far outside fp16: no planes are involved
+    W = torch.from_numpy(synth.hash_normal("W", (N, K), 53) / np.sqrt(K)).float()
+    b = torch.from_numpy(synth.hash_normal("b", (N,), 54)).float() * 3e5
+    ps = torch.from_numpy(0.5 + synth.hash_uniform("ps", (N,), 55)).float() if post else None
+    pt = torch.from_numpy(synth.hash_normal("pt", (N,), 56)).float() if post else None
+    ref = X.double() @ W.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    if post:
+        ref = ref * ps.double() + pt.double()
+    cu = lambda t: None if t is None else t.cuda()            # noqa: E731
+    outs = {}
+    for prec in ("f32", "f16x2", "bf16"):
+        ya = ops.range_record(M, "cuda")
+        outs[prec] = ops.dense(X.cuda(), W.cuda(), b.cuda(), relu, cu(ps), cu(pt), precision=prec, skinny=True, y_amax=ya, y_group_rows=1)
+        if prec == "f16x2":
+            assert torch.equal(ops.range_values(ya).cpu(), outs[prec].abs().amax(1).cpu())
+    assert rel(outs["f32"], ref) < 2e-6
+    assert torch.equal(outs["f32"], outs["f16x2"]) and torch.equal(outs["f32"], outs["bf16"])
+    one = ops.dense(X[M // 2:M // 2 + 1].cuda().contiguous(), W.cuda(), b.cuda(), relu, cu(ps), cu(pt), precision="f16x2", skinny=True)
+    assert torch.equal(one[0], outs["f32"][M // 2])
+
+
 @pytest.mark.parametrize("wscale", [1e-2, 1e-4, 1e-6, 30.0])
 @pytest.mark.parametrize("N", [256, 22])
 def test_f16x2_weight_magnitude_does_not_matter(wscale, N):
