@@ -160,6 +160,13 @@ static const char* const kRangeNames[R_COUNT] = {
     "feat", "l1a", "l1b", "l2", "sa3h1", "sa3h2", "l3", "fp3h", "fp3o", "fp2h", "l1new", "fp1in", "fp1h1", "fp1h2", "l0", "clsh", "q1",
     "hfL", "hfR", "m1L", "m1R", "msa2hL", "msa2hR", "m2L", "m2R", "fc1L", "fc1R", "p1a", "p1b", "p1mL", "p1mR", "fp1t"};
 
+// A/B switch (EV2H_ATTN_UNFOLDED=1): the second query convolution as two k=3 GEMMs + ev2h_attn_sim; only then does the workspace
+// hold their output (4.2 MB per window)
+static bool attn_unfolded() {
+    static const bool on = getenv("EV2H_ATTN_UNFOLDED") != nullptr;
+    return on;
+}
+
 static void build_layout(Layout& L, int B, int N) {
     const size_t R = (size_t)B * N;
     const size_t b = (size_t)B;
@@ -196,7 +203,7 @@ static void build_layout(Layout& L, int B, int N) {
     L.add("clsh", R * 256);
     L.add("logits_pm", R * 4);
     L.add("q1", R * 512);
-    L.add("q2", 2 * R * 256);
+    if (attn_unfolded()) L.add("q2", 2 * R * 256);
     L.add("zpart", ev2h_attn_sim_folded_scratch(B, N));
     L.add("sim", b * 2 * 4 * 256);
     L.add("hf8", 2 * R * 8);
@@ -502,7 +509,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N, R_Q1, N), nullptr, 0, 0, 3, N));
     // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
     // over the points (ev2h_attn_sim_folded): q2 is never formed
-    static const bool unfolded = getenv("EV2H_ATTN_UNFOLDED") != nullptr;        // A/B switch: the two k=3 GEMMs + ev2h_attn_sim
+    const bool unfolded = attn_unfolded();
     if (unfolded) {
         for (int h = 0; h < 2; ++h)
             RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));

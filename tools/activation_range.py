@@ -14,7 +14,7 @@ for kind in ("E", "U"):
     with torch.no_grad(): net(xyz)
     torch.cuda.synchronize()
     out = []
-    for name in ("P1a", "l1cat", "P1b", "l2buf", "sa3h1", "sa3h2", "l3", "fp3o", "fp2h", "l1new", "fp1T", "l0", "clsh", "q1", "q2",
+    for name in ("P1a", "l1cat", "P1b", "l2buf", "sa3h1", "sa3h2", "l3", "fp3o", "fp2h", "l1new", "fp1T", "l0", "clsh", "q1",
                  "P1mL", "m1bufL", "msa2hL", "m2L", "fc1L"):
         t = net.net.debug_buffer(name)
         out.append(f"{name} {float(t.abs().max()):.3g}")

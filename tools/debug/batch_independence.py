@@ -16,7 +16,7 @@ xyz[1, 3:] *= float(os.environ.get("DBG_MAG", "1e4"))
 inits = synth.fps_inits(2, N, seed)
 names = [("feat8", N * 8), ("P1a", N * 160), ("l1cat", 512 * 576), ("P1b", 512 * 256), ("l2buf", 128 * 520), ("sa3h1", 128 * 256), ("sa3h2", 128 * 512),
          ("l3", 1024), ("fp3bias", 256), ("fp3h", 128 * 256), ("fp3o", 128 * 256), ("fp2h", 512 * 256), ("l1new", 512 * 128), ("fp1T", 512 * 128),
-         ("l0", N * 256), ("clsh", N * 256), ("logits_pm", N * 4), ("q1", N * 512), ("q2", N * 256),
+         ("l0", N * 256), ("clsh", N * 256), ("logits_pm", N * 4), ("q1", N * 512),
          ("sim", 2 * 4 * 256), ("hf8", N * 8), ("P1mL", N * 256), ("m1bufL", 128 * 520), ("msa2hL", 128 * 256), ("m2L", 512), ("fc1L", 1024)]
 recs = ["feat", "l1a", "l1b", "l2", "sa3h1", "sa3h2", "l3", "fp3h", "fp3o", "fp2h", "l1new", "fp1t", "l0", "clsh", "q1", "hfL", "hfR",
         "m1L", "msa2hL", "m2L", "fc1L", "p1a", "p1b", "p1mL"]
