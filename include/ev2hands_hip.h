@@ -32,13 +32,16 @@ extern "C" {
 typedef void* ev2h_stream_t; /* hipStream_t */
 
 /* Arithmetic of the MFMA contractions (selections, biases, ReLU, max, MANO are always fp32):
- *  F32     v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (default);
+ *  F32     v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation;
  *  BF16X3  each fp32 operand split exactly into 3 bf16 planes, 6 plane products on
  *          v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class accuracy (dropped terms O(2^-24));
  *  F16X2   each fp32 operand split into 2 fp16 planes (11 + 11 mantissa bits), 3 plane products on
  *          v_mfma_f32_32x32x16_f16 with fp32 accumulation: dropped terms O(2^-22), operands must stay below 65504
  *          in magnitude (weights are checked at pack time), absolute error <= 2^-25 for tiny operands;
- *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3). */
+ *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3).
+ * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the K = 8
+ * layer-1 tables of the raw cloud, the one-row-per-window layers (ev2h_gemm_desc.skinny) and the folded attention product
+ * (ev2h_attn_sim_folded). */
 #define EV2H_PREC_F32 0
 #define EV2H_PREC_BF16 1
 #define EV2H_PREC_F16X2 2
