@@ -70,7 +70,8 @@ struct SaBCfg {
     static constexpr int TB3 = 32 * RS3;
     // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
     // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
-    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4 + 16;   // W1x, b2, one int for the workgroup's strip count
+    static constexpr int SB2W = (NS == 2) ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
+    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4 + 16 + SB2W;   // W1x, b2, one int for the workgroup's strip count, scaled b2
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
     static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
     static constexpr int CPT = fits(2) ? 2 : 1, UPT = CPT;
@@ -78,7 +79,7 @@ struct SaBCfg {
     static constexpr int LDS_BYTES = 2 * TILE + SMALL;
     // resident variant: every tile image of the module stays in LDS for the lifetime of the (persistent) workgroup
     static constexpr int RES_W = (NC1 * TB2 + T3 * TB3 + 1023) / 1024 * 1024;
-    static constexpr int RES_LDS_BYTES = RES_W + C1 * 16 + T2 * 32 * 4 + 16;
+    static constexpr int RES_LDS_BYTES = RES_W + SMALL;
     static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
 };
@@ -119,6 +120,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
     }
     for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
+    // F16X2: the accumulators hold (s1 / u2)(W2 h1 + b2) with the window's power of two s1; each wave keeps b2 s1 / u2 of its
+    // window here, so that an accumulator tile is initialised by four LDS reads and no arithmetic
+    float* sbw = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + C1 * 16 + T2 * 32 * 4 + 16) + wave * (T2 * 32) : sb2;
 
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
     auto dma_tile = [&](const char* src, char* dst, int bytes) {
@@ -185,6 +189,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         s1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s1)));
         c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c2)));
         c3 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c3)));
+        for (int i = lane; i < T2 * 32; i += 64) sbw[i] = sb2[i] * s1;           // read back by this wave only (LDS ops of a wave stay in order)
     }
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         for (int t = 0; t < T2; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb2 + 32 * t + 8 * j + 4 * half);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbw + 32 * t + 8 * j + 4 * half);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h2[t][4 * j + e] = (NS == 2) ? bv[e] * s1 : bv[e];
+                for (int e = 0; e < 4; ++e) h2[t][4 * j + e] = bv[e];
             }
 
 #ifdef EV2H_SAB_TIMELINE
@@ -379,8 +384,22 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         STAMP(39);
 
         // ---------------- layer 3 + max: D3[neighbour][channel] = H2 (A, registers) x W3 tile (B, LDS, permuted k order)
+        // set abstraction: the max over the strip's neighbours, kept per output tile
+        auto finish_tile = [&](int u, const f32x16& acc) {
+            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, acc[15]);
+#pragma unroll
+            for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
+        };
+        // TPS = 2 (two tiles resident per step: every MLP but 32-32-64): the two tiles' accumulators take alternate MFMAs (consecutive
+        // MFMAs never depend on each other) and share the activation fragments; TPS = 1: one tile, two accumulators that are summed
+        // (the row chains keep one tile at a time: their store addresses would not fit the scalar registers twice)
+        constexpr int TPS = (!ROWS && (RES || UPT == 2)) ? 2 : 1;
+        static_assert(T3 % TPS == 0, "layer-3 tiles are walked in pairs");
 #pragma unroll 1
-        for (int u = 0; u < T3; ++u) {
+        for (int u = 0; u < T3; u += TPS) {
             STAMP(40 + 4 * u);
             char* cur = RES ? smem + NC1 * Cfg::TB2 + u * Cfg::TB3 : (buf ? wt1 : wt0) + (u % UPT) * Cfg::TB3;
             char* nxt = buf ? wt0 : wt1;
@@ -391,7 +410,6 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     if (more_w3) dma_w3(u / UPT + 1, nxt); else if (more) dma_w2(0, nxt);
                 }
             }
-            // two accumulators take alternate plane products (see layer 2); their sum is the tile
             f32x16 acc, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
@@ -401,55 +419,61 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     if (t < T2 - 1 || m < Cfg::M_LAST) {
-                        u32x4 a[NS], w[NS];
+                        u32x4 a[NS], w[NS], w1[TPS == 2 ? NS : 1];
 #pragma unroll
                         for (int s = 0; s < NS; ++s) {
                             a[s] = h2p[s][t][m];
                             w[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (32 * t + 16 * m) * 2);
+                            if constexpr (TPS == 2) w1[s] = *reinterpret_cast<const u32x4*>(pb + Cfg::TB3 + s * (C2P * 2) + (32 * t + 16 * m) * 2);
                         }
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
 #pragma unroll
                         for (int j = 0; j < PL::NPROD; ++j) {
-                            if (((2 * t + m) * PL::NPROD + j) & 1) acc1 = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc1);
-                            else acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
+                            if constexpr (TPS == 2) {
+                                acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
+                                acc1 = mfma_planes<NS>(a[PL::A[j]], w1[PL::B[j]], acc1);
+                            } else {
+                                if (((2 * t + m) * PL::NPROD + j) & 1) acc1 = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc1);
+                                else acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
+                            }
                         }
                     }
                 }
             }
             STAMP(41 + 4 * u);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
-            if constexpr (ROWS) {
-                // D3[point][channel]: this lane holds channel 32u + l31 of the points 8(r/4) + 4 half + r%4 -- one store
-                // instruction writes two 128-byte row segments
-                float b3u = b3r[0];
-#pragma unroll
-                for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
-                float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
-                const bool colok = valid && (32 * u + l31 < p.ncols);
-                float* ocm = p.out_cm ? p.out_cm + ((size_t)b * p.ncols + 32 * u + l31) * p.N + row0 + 4 * half : nullptr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int pt = 8 * (r >> 2) + (r & 3);
-                    float o = acc[r] * c3 + b3u;
-                    if (p.relu_out) o = fmaxf(o, 0.f);
-                    if (colok && row0 + 4 * half + pt < p.N) {
-                        orow[(size_t)pt * p.ldo] = o;
-                        if (ocm) ocm[pt] = o;
-                        am = max(am, abs_bits(o));
-                    }
-                }
+            if constexpr (TPS == 2) {
+                finish_tile(u, acc);
+                finish_tile(u + 1, acc1);
             } else {
-            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
-            mx = fmaxf(mx, acc[15]);
-#pragma unroll
-            for (int uu = 0; uu < T3; ++uu) mrun[uu] = (uu == u) ? fmaxf(mrun[uu], mx) : mrun[uu];
+                for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+                if constexpr (ROWS) {
+                    // D3[point][channel]: this lane holds channel 32u + l31 of the points 8(r/4) + 4 half + r%4 -- one store
+                    // instruction writes two 128-byte row segments
+                    float b3u = b3r[0];
+    #pragma unroll
+                    for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
+                    float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
+                    const bool colok = valid && (32 * u + l31 < p.ncols);
+                    float* ocm = p.out_cm ? p.out_cm + ((size_t)b * p.ncols + 32 * u + l31) * p.N + row0 + 4 * half : nullptr;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pt = 8 * (r >> 2) + (r & 3);
+                        float o = acc[r] * c3 + b3u;
+                        if (p.relu_out) o = fmaxf(o, 0.f);
+                        if (colok && row0 + 4 * half + pt < p.N) {
+                            orow[(size_t)pt * p.ldo] = o;
+                            if (ocm) ocm[pt] = o;
+                            am = max(am, abs_bits(o));
+                        }
+                    }
+                } else {
+                    finish_tile(u, acc);
+                }
             }
             STAMP(42 + 4 * u);
             if constexpr (!RES) {
-                if (u % UPT == UPT - 1) {
+                if ((u + TPS - 1) % UPT == UPT - 1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
                     buf ^= 1;
