@@ -94,7 +94,7 @@ def test_range_records_hold_the_exact_maxima():
     dbg = net.net.debug_buffer
     for rec, buf, shape, cols in (("l0", "l0", (B, N, 256), slice(0, 256)), ("l1a", "l1cat", (B, 512, 576), slice(0, 320)),
                                   ("l1b", "l1cat", (B, 512, 576), slice(320, 576)), ("l2", "l2buf", (B, 128, 520), slice(0, 512)),
-                                  ("q1", "q1", (B, N, 512), slice(0, 512)), ("l1new", "l1new", (B, 512, 128), slice(0, 128)),
+                                  ("fp2h", "fp2h", (B, 512, 256), slice(0, 256)), ("l1new", "l1new", (B, 512, 128), slice(0, 128)),
                                   ("l3", "l3", (B, 1, 1024), slice(0, 1024)), ("fc1L", "fc1L", (B, 1, 1024), slice(0, 1024)),
                                   ("feat", "feat8", (B, N, 8), slice(0, 8)), ("hfR", "hf8", (2, B, N, 8), None)):
         got = dbg("rng." + rec).view(torch.float32)[:B]
