@@ -345,6 +345,7 @@ def run_rank(a) -> int:
         except Exception as e:  # noqa: BLE001 -- a latency leg must never lose the throughput line
             latency = {"error": f"{type(e).__name__}: {e}"}
 
+    line = None
     if rank == 0:
         res = {
             "metric": f"event-windows/sec at B={B} N={N}" + ("" if a.stub else f" ({a.precision})"),
@@ -376,9 +377,18 @@ def run_rank(a) -> int:
                 res["latency_ms"] = latency
             if world == 1 and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
     if use_dist:
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner to the C-level stdout, which -- when stdout is a pipe or a file -- sits in libc's buffer until
+        # exit and would land AFTER the result: flush it first, so that the JSON line is the last thing this process prints
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
     return 0
 
 
