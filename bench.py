@@ -378,16 +378,22 @@ def run_rank(a) -> int:
             if world == 1 and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         line = json.dumps(res)
-    if use_dist:
-        dist.destroy_process_group()
-    if line is not None:
-        # RCCL writes its version banner to the C-level stdout, which -- when stdout is a pipe or a file -- sits in libc's buffer until
-        # exit and would land AFTER the result: flush it first, so that the JSON line is the last thing this process prints
+    # RCCL writes its version banner to the C-level stdout, which -- when stdout is a pipe or a file -- sits in libc's buffer until
+    # exit and would land AFTER the result (from any rank: a launcher merges the ranks' stdout).  Every rank flushes it, then a
+    # barrier, then the group is destroyed, and only then rank 0 prints: the JSON line is the last thing on stdout.
+    def flush_c_stdout():
         try:
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+
+    flush_c_stdout()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        flush_c_stdout()
         print(line, flush=True)
     return 0
 
