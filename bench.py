@@ -66,6 +66,9 @@ def parse(argv=None):
     ap.add_argument("--no-legs", "--no-f32-leg", dest="no_legs", action="store_true", help="skip the timing legs of the other arithmetic modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--collision", action="store_true",
+                    help="BASELINE config 5: add the two-hand self-collision term to every step (pair search with the evaluation's "
+                         "max_collisions = 8, then the intersection loss's pair search with 16 and its distance-field penalty)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--stub", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (launcher, gloo all-gather, max-over-ranks timing) with fabricated "
@@ -280,10 +283,20 @@ def run_rank(a) -> int:
         L = _lib.lib()
         ev = HipEvents(max(a.steps, 1))
 
+        closs = None
+        if a.collision:
+            from ev2hands_amd import collision as evcol
+            closs = evcol.CollisionLoss(dev)
+
         def forward():
             net.net.fps_init = inits
             with torch.no_grad():
-                return net(xyz)
+                out = net(xyz)
+                if closs is not None:          # all device-side, no host synchronisation (evaluate_ev2hands_r.py:128-160, losses.py:60-102)
+                    fl, fr = net.hands["left"].faces, net.hands["right"].faces
+                    out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], fl, fr, max_per_triangle=8)
+                    out["collision_penalty"] = closs.per_window(out)
+                return out
 
     def step():
         out = forward()
@@ -356,7 +369,8 @@ def run_rank(a) -> int:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "stub" if a.stub else DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
-                                   f"random-init 342-key checkpoint, synthetic MANO-shaped assets",
+                                   f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
+                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16) per window" if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if use_dist else "")},
