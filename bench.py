@@ -370,7 +370,8 @@ def run_rank(a) -> int:
             "dtype": "stub" if a.stub else DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
                                    f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
-                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16) per window" if a.collision else ""),
+                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16) per window (the synthetic hand meshes are random geometry "
+                                      "and intersect themselves ~24 000 times: worst case for the pair search)" if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
                        "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if use_dist else "")},
