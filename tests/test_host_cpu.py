@@ -54,6 +54,16 @@ def test_bad_arguments_return_error_codes_not_crashes(built):
     assert built.ev2h_sa_mlp_max(C.byref(s), None) != 0
     f = _lib.FpDesc()
     assert built.ev2h_fp_mlp(C.byref(f), None) != 0
+    # a chain shape the fused row kernel does not have: a clean error before anything is launched
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p).value
+    f.T, f.ldt, f.b2, f.b3, f.W2s, f.W3s, f.out, f.ldo = p, 64, p, p, p, p, p, 64
+    f.B, f.N, f.C1, f.C2, f.C3, f.precision = 1, 32, 64, 64, 64, _lib.PREC["f16x2"]
+    assert built.ev2h_fp_mlp(C.byref(f), None) != 0 and b"unsupported chain" in built.ev2h_last_error()
+    f.ldt, f.C1, f.C2, f.C3, f.precision = 256, 256, 256, 32, _lib.PREC["f32"]
+    assert built.ev2h_fp_mlp(C.byref(f), None) != 0 and b"16-bit" in built.ev2h_last_error()
+    assert built.ev2h_attn_sim_folded(None, None, 512, 1, 128, None, None, None, None, None, None, None) != 0
+    assert built.ev2h_attn_sim_folded_scratch(2, 2048) == 2 * 8 * 12 * 512 and built.ev2h_attn_sim_folded_scratch(1, 130) == 12 * 512
 
 
 def test_checkpoint_schema():
