@@ -400,6 +400,7 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     static const bool no_skinny = getenv("EV2H_NO_SKINNY_KERNEL") != nullptr;      // A/B switch
     if (d->skinny && !no_skinny) {
         EV2H_CHECK_ARG(d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->y_scale);
+        EV2H_CHECK_ARG(d->M <= 8 * 65535);                       // grid.y; the kernel is meant for M = number of windows anyway
         SkinnyP q{};
         q.X = d->X; q.ldx = d->ldx; q.W = d->W; q.ldw = d->ldw; q.Y = d->Y; q.ldy = d->ldy; q.M = d->M; q.N = d->N; q.K = d->K;
         q.bias = d->bias; q.relu = d->relu; q.post_scale = d->post_scale; q.post_shift = d->post_shift;
