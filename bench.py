@@ -87,39 +87,60 @@ def _free_port() -> int:
 
 def launch_ranks(a, argv) -> int:
     """`python bench.py --gpus N` without a launcher: start one child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-    set as torch.distributed.run would), wait for them and relay rank 0's JSON line.  Runs before any HIP call; the parent
-    never initialises the GPU."""
+    set as torch.distributed.run would), watch them and relay rank 0's JSON line.  Runs before any HIP call; the parent never
+    initialises the GPU.  Every rank's stdout + stderr go to gpurun_out/bench_rank<r>.log (kept: gpurun merges that directory
+    back); the first rank that exits non-zero ends the run -- the others are terminated (exactly the children started here)
+    instead of waiting in RCCL for a peer that is gone -- and the tail of every failed rank's log is printed."""
     env = dict(os.environ)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = str(_free_port())
     env["WORLD_SIZE"] = str(a.gpus)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: required by RCCL on this driver
-    procs = []
+    logdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for r in range(a.gpus):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            p.kill()                                         # exactly the child we started
-            rcs.append(p.wait())
+        path = os.path.join(logdir, f"bench_rank{r}.log")
+        f = open(path, "w")
+        logs.append(path)
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e, stdout=f, stderr=subprocess.STDOUT), f))
+    deadline = time.time() + float(os.environ.get("EV2H_BENCH_LAUNCH_TIMEOUT", 3600))
+    rcs = [None] * a.gpus
+    failed = False
+    while any(rc is None for rc in rcs):
+        for r, (p, _) in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        for r, (p, _) in enumerate(procs):
+            if rcs[r] is None:
+                p.terminate()
+        for r, (p, _) in enumerate(procs):
+            if rcs[r] is None:
+                try:
+                    rcs[r] = p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    rcs[r] = p.wait()
+    for _, f in procs:
+        f.close()
     line = None
-    for ln in (out0 or "").splitlines():
+    for ln in open(logs[0], errors="replace").read().splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if line is not None:
+    if line is not None and not failed:
         print(line, flush=True)
-    rc = max((abs(r) for r in rcs), default=0)
-    if rc or line is None:
-        sys.stderr.write(f"bench.py launcher: rank return codes {rcs}, rank-0 JSON line {'found' if line else 'MISSING'}\n")
-        if out0:
-            sys.stderr.write(out0[-2000:])
-        return rc or 1
-    return 0
+        return 0
+    sys.stderr.write(f"bench.py launcher: rank return codes {rcs}, rank-0 JSON line {'found' if line else 'MISSING'}; logs: {logdir}/bench_rank*.log\n")
+    for r, path in enumerate(logs):
+        if rcs[r] != 0 or line is None:
+            sys.stderr.write(f"---- tail of rank {r} (rc {rcs[r]}) ----\n" + open(path, errors="replace").read()[-3000:] + "\n")
+    return max((abs(rc) for rc in rcs if rc), default=0) or 1
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -237,6 +258,9 @@ def run_rank(a) -> int:
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus}, or run "
                          f"`python bench.py --gpus {a.gpus}` directly and let it start the ranks)")
+    if a.stub and os.environ.get("EV2H_BENCH_STUB_FAIL_RANK") == str(rank):          # launcher self-test: a rank that dies at start-up
+        sys.stderr.write(f"stub rank {rank}: simulated start-up failure\n")
+        return 3
     # EV2H_BENCH_FORCE_DIST=1 runs the RCCL code path (init, all-gather, barrier, all-reduce) with a single rank
     use_dist = world > 1 or bool(os.environ.get("EV2H_BENCH_FORCE_DIST"))
     if a.stub:
@@ -253,7 +277,8 @@ def run_rank(a) -> int:
         if a.stub:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            import datetime
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=float(os.environ.get("EV2H_BENCH_RCCL_TIMEOUT", 300))))
         world_seen = dist.get_world_size()
     else:
         world_seen = 1
@@ -267,7 +292,7 @@ def run_rank(a) -> int:
     if a.stub:
         net = L = ev = sd = assets = None
 
-        def forward():
+        def forward(rows=None):
             return stub_outputs(hi - lo, N, rank)
     else:
         from ev2hands_amd import _lib
@@ -283,26 +308,36 @@ def run_rank(a) -> int:
         L = _lib.lib()
         ev = HipEvents(max(a.steps, 1))
 
-        closs = None
+        closs = dev_faces = None
         if a.collision:
             from ev2hands_amd import collision as evcol
             closs = evcol.CollisionLoss(dev)
+            dev_faces = (evcol.device_faces(net.hands["left"].faces, dev), evcol.device_faces(net.hands["right"].faces, dev))   # converted ONCE
 
-        def forward():
+        def forward(rows=None):
             net.net.fps_init = inits
             with torch.no_grad():
-                out = net(xyz)
-                if closs is not None:          # all device-side, no host synchronisation (evaluate_ev2hands_r.py:128-160, losses.py:60-102)
-                    fl, fr = net.hands["left"].faces, net.hands["right"].faces
-                    out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], fl, fr, max_per_triangle=8)
-                    out["collision_penalty"] = closs.per_window(out)
+                out = net.net(xyz, net.hands, rows=rows)
+                if closs is not None:
+                    # device-side only: the face tables were uploaded in the set-up (a pageable host->device copy per call would
+                    # synchronise the stream six times per step); evaluate_ev2hands_r.py:128-160, losses.py:60-102
+                    out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], dev_faces[0], dev_faces[1],
+                                                                      max_per_triangle=8)
+                    out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
                 return out
 
+    # multi-GPU: the forward writes its windows straight into this rank's slice of the persistent gather buffer (ev2h_outputs'
+    # window strides), then ONE in-place all-gather -- no packing copy, no allocation per step
+    gbuf = evdist.GatherBuffer(N, gB, dev) if use_dist else None
+
     def step():
-        out = forward()
-        if use_dist:
-            out = evdist.all_gather_outputs(out, N, global_batch=gB)
-        return out
+        if gbuf is None:
+            return forward()
+        if a.stub:
+            gbuf.rows().copy_(evdist.pack_outputs(forward()))
+        else:
+            forward(gbuf.rows())
+        return gbuf.gather()
 
     def sync():
         if use_dist:
@@ -370,11 +405,12 @@ def run_rank(a) -> int:
             "dtype": "stub" if a.stub else DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
                                    f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
-                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16) per window (the synthetic hand meshes are random geometry "
-                                      "and intersect themselves ~24 000 times: worst case for the pair search)" if a.collision else ""),
+                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16, pair list sized 2 x 1538 x 16 per window: never "
+                                      "truncated) per window (the synthetic hand meshes are random geometry and intersect themselves ~24 000 times: worst case "
+                                      "for the pair search)" if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
-                       "parallelism": f"batch-shard x{world}" + (" + RCCL all-gather of predictions" if use_dist else "")},
+                       "parallelism": f"batch-shard x{world}" + (" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer)" if use_dist else "")},
         }
         if a.stub:
             res["stub"] = True

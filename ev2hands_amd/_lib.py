@@ -40,7 +40,7 @@ class FpDesc(C.Structure):
                 ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("out", vp), ("ldo", ci),
                 ("B", ci), ("N", ci), ("S", ci), ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci),
                 ("t_scale", vp), ("t_amax", vp), ("w2_norm", C.c_float), ("b2_max", C.c_float), ("out_amax", vp),
-                ("out_cols", ci), ("no_relu_out", ci), ("out_cm", vp)]
+                ("out_cols", ci), ("no_relu_out", ci), ("out_cm", vp), ("out_cm_stride", C.c_size_t)]
 
 
 class SaBranch(C.Structure):
@@ -66,7 +66,7 @@ class Weights(C.Structure):
                 ("cls0", Dense), ("cls4", Dense), ("clsm", SaBranch),
                 ("qconv0", Dense), ("qconv4", Dense * 2), ("qconv4T", vp * 2),
                 ("mano_sa2", (Dense * 2) * 2),
-                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci)]
+                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci), ("l0_unscale", vp)]
 
 PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
 
@@ -78,13 +78,14 @@ class ManoConsts(C.Structure):
 
 
 class Outputs(C.Structure):
-    _fields_ = [("class_logits", vp), ("params", vp * 2), ("vertices", vp * 2), ("joints", vp * 2)]
+    _fields_ = [("class_logits", vp), ("params", vp * 2), ("vertices", vp * 2), ("joints", vp * 2),
+                ("logits_stride", C.c_size_t), ("params_stride", C.c_size_t), ("vertices_stride", C.c_size_t), ("joints_stride", C.c_size_t)]
 
 
 EXPORTS = [
     "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
-    "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp",
+    "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
     "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
@@ -122,15 +123,16 @@ def lib() -> C.CDLL:
     L.ev2h_ball_query.argtypes = [vp, vp, ci, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(ci), C.POINTER(vp), vp, vp]
     L.ev2h_three_nn_interp.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, vp, ci, vp, vp, vp, vp]
     L.ev2h_gemm.argtypes = [C.POINTER(GemmDesc), vp]
-    L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, vp]
+    L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, C.c_size_t, vp]
     L.ev2h_sa_mlp_max.argtypes = [C.POINTER(SaDesc), vp]
     L.ev2h_fp_mlp.argtypes = [C.POINTER(FpDesc), vp]
+    L.ev2h_tile_geometry.argtypes = [ci, ci, ci, ci, C.c_int * 8]
     L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
-    L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp]
+    L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.ev2h_attn_sim_folded_scratch.restype = C.c_size_t
     L.ev2h_attn_sim_folded_scratch.argtypes = [ci, ci]
     L.ev2h_attn_sim_folded.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
-    L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp, vp]
+    L.ev2h_mano.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, C.c_size_t, vp, C.c_size_t, vp]
     L.ev2h_mano_rotations.argtypes = [C.POINTER(ManoConsts), vp, ci, ci, vp, vp]
     L.ev2h_forward.argtypes = [C.POINTER(Weights), C.POINTER(ManoConsts), C.POINTER(ManoConsts), vp, ci, ci, ci, ci, vp,
                                C.POINTER(Outputs), vp, C.c_size_t, vp]
@@ -146,7 +148,7 @@ def lib() -> C.CDLL:
     mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs, FpDesc)]
     if list(sizes) != mine:
         raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
-    if L.ev2h_abi_version() != 4:      # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m
+    if L.ev2h_abi_version() != 5:      # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs
         raise Ev2hError("ABI version mismatch")
     _lib = L
     return L

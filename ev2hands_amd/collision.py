@@ -16,7 +16,18 @@ from . import _lib
 
 
 def _faces(f, dev):
+    """faces [nf,3] (ndarray or tensor) as a contiguous int32 tensor on `dev`.  A tensor that already is one is returned as it is
+    (no copy, no synchronisation): callers on a hot path convert ONCE (device_faces) and pass the result."""
+    if torch.is_tensor(f) and f.dtype == torch.int32 and f.device == torch.device(dev) and f.is_contiguous():
+        return f
     return torch.as_tensor(np.asarray(f.cpu() if torch.is_tensor(f) else f).astype(np.int32)).to(dev).contiguous()
+
+
+def device_faces(faces, dev) -> torch.Tensor:
+    """One-time conversion of a hand model's `.faces` (ndarray [nf,3], or the [B,nf,3] tiling the eval forward returns) for the
+    functions below; a pageable host->device copy synchronises the stream, so it does not belong into a per-step call."""
+    a = np.asarray(faces.cpu() if torch.is_tensor(faces) else faces)
+    return _faces(a[0] if a.ndim == 3 else a, dev)
 
 
 def mesh_collisions(verts_left: torch.Tensor, verts_right: torch.Tensor, faces_left, faces_right, max_pairs: int = 0,
@@ -51,28 +62,67 @@ class CollisionLoss:
     """Value of the reference's intersection-aware loss term (/root/reference/src/Ev2Hands/losses.py:60-102) for a batch of
     predictions: colliding triangle pairs of the concatenated two-hand mesh in METRES (max_collisions = 16 per triangle), their
     conic distance-field penetration penalty (sigma = 0.5), mean over the windows with a non-zero penalty, times
-    collision_weight = 100.  Forward value only (the path is inference); parity unpinned (un-vendored torch-mesh-isect)."""
+    collision_weight = 100.  Forward value only (the path is inference); parity unpinned (un-vendored torch-mesh-isect).
 
-    def __init__(self, device=None, max_collisions: int = 16, sigma: float = 0.5, collision_weight: float = 1e2, max_pairs: int = 8192):
+    Deviation from upstream for B > 1 (documented): losses.py:88-93 builds the triangles with
+    `verts_tensor.view([-1, 3])[face_tensor]` WITHOUT offsetting the face indices per batch item, so every item indexes item 0's
+    vertices and the upstream value is 100 x the penalty of window 0 alone.  Here every window uses its own vertices (what the
+    code evidently means); `reference_batch_quirk=True` reproduces the upstream value instead.
+
+    max_pairs: capacity of the per-window pair list; default 2 * nf * max_collisions, the most a capped search can return, so the
+    penalty is never computed over a silently truncated list.  With an explicit smaller capacity `truncated(counts)` tells."""
+
+    def __init__(self, device=None, max_collisions: int = 16, sigma: float = 0.5, collision_weight: float = 1e2, max_pairs: int | None = None,
+                 reference_batch_quirk: bool = False):
         self.max_collisions, self.sigma, self.collision_weight, self.max_pairs = max_collisions, sigma, collision_weight, max_pairs
+        self.reference_batch_quirk = reference_batch_quirk
+        self._faces_key, self._faces_dev = None, None
+        self.last_counts = None
 
-    def per_window(self, outs) -> torch.Tensor:
+    def _device_faces(self, fl, fr, dev):
+        """the two face tables on the device, converted once per (object, device)"""
+        key = (id(fl), id(fr), str(dev))
+        if self._faces_key != key:
+            self._faces_dev = (device_faces(fl, dev), device_faces(fr, dev), fl, fr)       # (the originals are kept: ids stay unique)
+            self._faces_key = key
+        return self._faces_dev[0], self._faces_dev[1]
+
+    def capacity(self, nf: int) -> int:
+        if self.max_pairs is not None:
+            return int(self.max_pairs)
+        if self.max_collisions <= 0:
+            raise ValueError("an uncapped pair search (max_collisions = 0) needs an explicit max_pairs")
+        return 2 * nf * self.max_collisions
+
+    def per_window(self, outs, faces=None) -> torch.Tensor:
+        """[B] float64 penalties.  faces: optional (faces_left, faces_right) overriding outs[side]['faces'] (e.g. device_faces()
+        tensors prepared once)."""
         vl, vr = outs["left"]["vertices"], outs["right"]["vertices"]
-        fl, fr = outs["left"]["faces"], outs["right"]["faces"]
-        fl, fr = (f[0] if np.asarray(f).ndim == 3 else f for f in (fl, fr))         # eval outputs tile the faces per window
-        counts, pairs = mesh_collisions(vl, vr, fl, fr, max_pairs=self.max_pairs, scale=1.0, max_per_triangle=self.max_collisions)
-        B, nv, _ = vl.shape
         dev = vl.device
+        fl, fr = faces if faces is not None else (outs["left"]["faces"], outs["right"]["faces"])
+        flt, frt = self._device_faces(fl, fr, dev)
+        if self.reference_batch_quirk:
+            vl, vr = vl[:1].expand_as(vl), vr[:1].expand_as(vr)                          # losses.py:88-93: every item reads item 0
+        cap = self.capacity(flt.shape[0])
+        counts, pairs = mesh_collisions(vl, vr, flt, frt, max_pairs=cap, scale=1.0, max_per_triangle=self.max_collisions)
+        self.last_counts = counts
+        B, nv, _ = vl.shape
         loss = torch.zeros(B, device=dev, dtype=torch.float64)
-        flt, frt = _faces(fl, dev), _faces(fr, dev)
         vlc, vrc = vl.to(torch.float32).contiguous(), vr.to(dev, torch.float32).contiguous()
         _lib.check(_lib.lib().ev2h_collision_penalty(vlc.data_ptr(), vrc.data_ptr(),
                                                      flt.data_ptr(), frt.data_ptr(), B, nv, flt.shape[0], 1.0, float(self.sigma),
-                                                     pairs.data_ptr(), counts.data_ptr(), self.max_pairs, loss.data_ptr(),
+                                                     pairs.data_ptr(), counts.data_ptr(), cap, loss.data_ptr(),
                                                      _lib.stream_handle()), "ev2h_collision_penalty")
         return loss
 
-    def __call__(self, outs):
-        loss = self.per_window(outs)
+    def truncated(self) -> bool:
+        """True if the last per_window() found more pairs in some window than its pair list holds (host synchronisation)."""
+        if self.last_counts is None:
+            return False
+        nf = self._faces_dev[0].shape[0]
+        return bool(int(self.last_counts.max()) > self.capacity(nf))
+
+    def __call__(self, outs, faces=None):
+        loss = self.per_window(outs, faces)
         nz = loss[loss != 0]
         return (nz.mean() * self.collision_weight).to(torch.float32) if nz.numel() else 0

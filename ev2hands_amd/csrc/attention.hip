@@ -172,15 +172,21 @@ __global__ __launch_bounds__(1024) void attn_simfold_kernel(const float* __restr
 constexpr int CTX_PTS_PER_WAVE = 32;
 __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restrict__ sim, const float* __restrict__ value,
                                                            int ldv, int N, size_t rows_total, float* __restrict__ hf8,
-                                                           unsigned* __restrict__ amax, int amax_hand_stride) {
+                                                           unsigned* __restrict__ amax, int amax_hand_stride,
+                                                           const float* __restrict__ value_unscale) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 w[2][4];
+    // value channel d enters as value[d] * value_unscale[d]: folded into this lane's sim weights once (powers of two: exact)
+    const float4 vu = value_unscale ? *reinterpret_cast<const float4*>(value_unscale + lane * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            w[h][c] = *reinterpret_cast<const float4*>(sim + (((size_t)b * 2 + h) * 4 + c) * ATT_D + lane * 4);
+        for (int c = 0; c < 4; ++c) {
+            float4 t = *reinterpret_cast<const float4*>(sim + (((size_t)b * 2 + h) * 4 + c) * ATT_D + lane * 4);
+            t.x *= vu.x; t.y *= vu.y; t.z *= vu.z; t.w *= vu.w;
+            w[h][c] = t;
+        }
     const int n0 = (blockIdx.x * 4 + wave) * CTX_PTS_PER_WAVE;
     unsigned am = 0u;
     for (int n = n0; n < n0 + CTX_PTS_PER_WAVE && n < N; ++n) {
@@ -254,10 +260,10 @@ extern "C" int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, 
 }
 
 extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax,
-                                 int amax_hand_stride, ev2h_stream_t stream) {
+                                 int amax_hand_stride, const float* value_unscale, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
     dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
-    attn_context_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride);
+    attn_context_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride, value_unscale);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -495,14 +495,14 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         ev2h_fp_desc d{};
         d.T = ws.f("l0"); d.ldt = 256; d.b2 = c.b2; d.b3 = c.b3; d.W2s = c.W2s; d.W3s = c.W3s;
         d.w2_unscale = c.w2_unscale; d.w3_unscale = c.w3_unscale;
-        d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits;
+        d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits; d.out_cm_stride = out->logits_stride;
         d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec;
         if (ws.ranges_on) { d.t_amax = ws.r(R_L0); d.w2_norm = c.w2_norm; d.b2_max = c.b2_max; }
         RUN(ev2h_fp_mlp(&d, sx));
     } else {
         RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
         RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
-        RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, sx));
+        RUN(ev2h_transpose_logits(ws.f("logits_pm"), B, N, out->class_logits, out->logits_stride, sx));
     }
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
@@ -522,7 +522,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(ev2h_attn_sim_folded(ws.f("logits_pm"), ws.f("q1"), 512, B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
                                  ws.f("zpart"), ws.f("sim"), st));
     }
-    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, st));
+    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, w->l0_unscale, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
     if (fork) {
         EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[1], 0));       // ball queries done
@@ -542,8 +542,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh, rg(R_M1 + h, 128, R_MSA2H + h, 128, R_FEAT)));
         RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, rg(R_MSA2H + h, 128, R_M2 + h, 1), nullptr, 0, 0, 1, 0, 128));
         RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh, rg(R_M2 + h, 1, R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
-        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], 22, 0, sh, rg(R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
-        if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], 22, B, out->vertices[h], out->joints[h], sh));
+        const int ldprm = out->params_stride ? (int)out->params_stride : 22;
+        RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], ldprm, 0, sh, rg(R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
+        if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], ldprm, B, out->vertices[h], out->vertices_stride, out->joints[h], out->joints_stride, sh));
     }
     return EV2H_OK;
 }
@@ -557,6 +558,9 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     // a NULL hand model skips that hand's MANO layer (the caller applies its own to params[h], TEHNet.py:103)
     EV2H_CHECK_ARG(!mano_left || (out->vertices[0] && out->joints[0]));
     EV2H_CHECK_ARG(!mano_right || (out->vertices[1] && out->joints[1]));
+    EV2H_CHECK_ARG((out->logits_stride == 0 || out->logits_stride >= (size_t)4 * N) && (out->params_stride == 0 || out->params_stride >= 22));
+    EV2H_CHECK_ARG(out->params_stride <= 0x7fffffff);
+    EV2H_CHECK_ARG((out->vertices_stride == 0 || out->vertices_stride >= 2334) && (out->joints_stride == 0 || out->joints_stride >= 63));
     EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
     EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
     RUN(ev2h_init());

@@ -272,12 +272,12 @@ __global__ __launch_bounds__(256) void table_k8_kernel(TableP p) {
 // tiny-N / odd-shape fallback is not needed: every other layer of the path goes through the tile above.
 
 // logits [B*N][4] point-major -> class_logits [B,4,N] (TEHNet.py:188 output layout)
-__global__ __launch_bounds__(256) void transpose_logits_kernel(const float4* __restrict__ pm, int N, float* __restrict__ cm) {
+__global__ __launch_bounds__(256) void transpose_logits_kernel(const float4* __restrict__ pm, int N, float* __restrict__ cm, size_t cm_stride) {
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const float4 v = pm[(size_t)b * N + n];
-    float* o = cm + (size_t)b * 4 * N + n;
+    float* o = cm + (size_t)b * cm_stride + n;
     o[0] = v.x; o[(size_t)N] = v.y; o[(size_t)2 * N] = v.z; o[(size_t)3 * N] = v.w;
 }
 
@@ -418,10 +418,12 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     return EV2H_OK;
 }
 
-extern "C" int ev2h_transpose_logits(const float* logits_pm, int B, int N, float* logits_cm, ev2h_stream_t stream) {
+extern "C" int ev2h_transpose_logits(const float* logits_pm, int B, int N, float* logits_cm, size_t cm_window_stride, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(logits_pm && logits_cm && B > 0 && N > 0);
+    EV2H_CHECK_ARG(cm_window_stride == 0 || cm_window_stride >= (size_t)4 * N);
     dim3 grid(ceil_div(N, 256), B);
-    transpose_logits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)logits_pm, N, logits_cm);
+    transpose_logits_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)logits_pm, N, logits_cm,
+                                                                   cm_window_stride ? cm_window_stride : (size_t)4 * N);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

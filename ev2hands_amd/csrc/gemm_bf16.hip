@@ -33,7 +33,6 @@ struct GemmBP {
     float* y_scale; float y_bound_w, y_bound_b;                           // out: Y is stored times the power of two that keeps
                                                                           // (y_bound_w * max|X| + y_bound_b) * s below 2^15
     int tiles_n; int nblk;
-    int debug;              // timing experiments only (EV2H_GEMM_DEBUG): bit0 skip W DMA after tile 0, bit1 skip X loads
 };
 
 template <int NS>
@@ -398,8 +397,8 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         const char* sB = (kt & 1) ? sB1 : sB0;
         const bool more = kt + 1 < nk;
         if (more) {                     // next tile: W by LDS-DMA, X rows into registers; both land under the MFMAs
-            if (!(p.debug & 1)) dma_b(kt + 1, (kt & 1) ? sB0 : sB1);
-            if (!(p.debug & 2)) gload(kt + 1);
+            dma_b(kt + 1, (kt & 1) ? sB0 : sB1);
+            gload(kt + 1);
         }
         const char* pa = sA + (wm * 64 + l31) * RS + half * 16;
         const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
@@ -648,6 +647,13 @@ int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
 
 }  // namespace
 
+// geometry of the W plane images of the fast kernels (ev2h_tile_geometry): bytes per LDS row, K columns per tile
+int ev2h_gemm_tile_geometry(int ns, int out[2]) {
+    out[0] = ns == 1 ? GBCfg<1>::RS : ns == 2 ? GBCfg<2>::RS : GBCfg<3>::RS;
+    out[1] = GB_BK;
+    return EV2H_OK;
+}
+
 // called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
 int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->K % 8) == 0);
@@ -670,8 +676,6 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     } else {
         p.x_group_rows = p.y_group_rows = 1;
     }
-    static const int dbg = getenv("EV2H_GEMM_DEBUG") ? atoi(getenv("EV2H_GEMM_DEBUG")) : 0;
-    p.debug = dbg;
     // range groups that do not tile by 128 rows (N % 128 != 0, or one row per group: the per-window head layers) take the
     // generic kernel with the per-row epilogue; everything on the hot path is tile aligned
     const bool general = (p.x_amax && p.x_group_rows % GB_BM != 0) ||

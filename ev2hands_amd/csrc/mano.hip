@@ -18,6 +18,7 @@ struct ManoP {
     ev2h_mano_consts c;
     const float* params; int ldp;
     float* verts; float* joints;
+    size_t verts_stride, joints_stride;       // floats between consecutive windows
 };
 
 // level-ordered chain: parents of joint k (MANO kintree), -1 for the root
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
 #pragma unroll
         for (int t = 0; t < 5; ++t)
             if (v == p.c.tips[t]) { s_tip[t][0] = o[0]; s_tip[t][1] = o[1]; s_tip[t][2] = o[2]; }
-        float* ov = p.verts + ((size_t)b * NV + v) * 3;
+        float* ov = p.verts + (size_t)b * p.verts_stride + v * 3;
         ov[0] = __fdiv_rn(__fmul_rn(__fadd_rn(o[0], trx), 1000.f), 1000.f);
         ov[1] = __fdiv_rn(__fmul_rn(__fadd_rn(o[1], try_), 1000.f), 1000.f);
         ov[2] = __fdiv_rn(__fmul_rn(__fadd_rn(o[2], trz), 1000.f), 1000.f);
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
         const int src = c_joint_reorder[tid];
         float j[3];
         for (int c = 0; c < 3; ++c) j[c] = (src < NJ) ? s_G[src][4 * c + 3] : s_tip[src - NJ][c];
-        float* oj = p.joints + ((size_t)b * 21 + tid) * 3;
+        float* oj = p.joints + (size_t)b * p.joints_stride + tid * 3;
         oj[0] = __fdiv_rn(__fmul_rn(__fadd_rn(j[0], trx), 1000.f), 1000.f);
         oj[1] = __fdiv_rn(__fmul_rn(__fadd_rn(j[1], try_), 1000.f), 1000.f);
         oj[2] = __fdiv_rn(__fmul_rn(__fadd_rn(j[2], trz), 1000.f), 1000.f);
@@ -194,13 +195,15 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
 
 }  // namespace
 
-extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, float* joints,
-                         ev2h_stream_t stream) {
+extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, size_t verts_stride, float* joints,
+                         size_t joints_stride, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(c && params && verts && joints && B > 0);
     EV2H_CHECK_ARG(c->hands_mean && c->comps && c->blend_T && c->v_template && c->J_template && c->J_shape && c->weights);
     EV2H_CHECK_ARG(c->ncomps >= 1 && c->ncomps <= 45 && ldp >= 3 + c->ncomps + 13);
     ManoP p{};
+    EV2H_CHECK_ARG((verts_stride == 0 || verts_stride >= (size_t)NV * 3) && (joints_stride == 0 || joints_stride >= 63));
     p.c = *c; p.params = params; p.ldp = ldp; p.verts = verts; p.joints = joints;
+    p.verts_stride = verts_stride ? verts_stride : (size_t)NV * 3; p.joints_stride = joints_stride ? joints_stride : 63;
     mano_kernel<<<B, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

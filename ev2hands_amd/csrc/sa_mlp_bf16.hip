@@ -42,7 +42,7 @@ struct SaBP {
     // MODE 2 (plain row chain, e.g. the segmentation head): P1 holds the N input rows themselves (no blend, no layer-1 ReLU; F16X2:
     // scaled here by the power of two of p1_amax); ncols = leading columns of the last tile that are written; relu_out = 0 drops
     // the last ReLU; out_cm = optional second copy of the output, channel-major [B][ncols][N]
-    int ncols; int relu_out; float* out_cm;
+    int ncols; int relu_out; float* out_cm; size_t out_cm_stride;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
                     float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
                     const bool colok = valid && (32 * u + l31 < p.ncols);
-                    float* ocm = p.out_cm ? p.out_cm + ((size_t)b * p.ncols + 32 * u + l31) * p.N + row0 + 4 * half : nullptr;
+                    float* ocm = p.out_cm ? p.out_cm + (size_t)b * p.out_cm_stride + (size_t)(32 * u + l31) * p.N + row0 + 4 * half : nullptr;
     #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int pt = 8 * (r >> 2) + (r & 3);
@@ -578,6 +578,36 @@ static int dispatch_fp(const SaBP& p, const ev2h_fp_desc* d, hipStream_t st) {
     return EV2H_ERR_ARG;
 }
 
+// The tile-image geometry the host packer must reproduce (ev2hands_amd/pack.py: sa_bf16_images, gemm_bf16_w_image): ONE source of
+// truth -- pack.py asserts its own numbers against this at load time.
+int ev2h_gemm_tile_geometry(int ns, int out[2]);
+namespace {
+template <int C1, int C2, int C3, int NS>
+int fill_geometry(int out[8]) {
+    using Cfg = SaBCfg<C1, C2, C3, NS>;
+    out[0] = Cfg::T2; out[1] = Cfg::C2P; out[2] = Cfg::RS2; out[3] = Cfg::RS3; out[4] = Cfg::TB2; out[5] = Cfg::TB3;
+    return EV2H_OK;
+}
+template <int NS>
+int geometry_ns(int c1, int c2, int c3, int out[8]) {
+    if (c1 == 32 && c2 == 32 && c3 == 64) return fill_geometry<32, 32, 64, NS>(out);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return fill_geometry<64, 64, 128, NS>(out);
+    if (c1 == 64 && c2 == 96 && c3 == 128) return fill_geometry<64, 96, 128, NS>(out);
+    if (c1 == 128 && c2 == 128 && c3 == 256) return fill_geometry<128, 128, 256, NS>(out);
+    if (c1 == 128 && c2 == 196 && c3 == 256) return fill_geometry<128, 196, 256, NS>(out);
+    if (c1 == 256 && c2 == 256 && c3 == 32) return fill_geometry<256, 256, 32, NS>(out);
+    return EV2H_ERR_ARG;
+}
+}  // namespace
+
+extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[8]) {
+    EV2H_CHECK_ARG(out && planes >= 1 && planes <= 3);
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    const int rc = planes == 1 ? geometry_ns<1>(C1, C2, C3, out) : planes == 2 ? geometry_ns<2>(C1, C2, C3, out) : geometry_ns<3>(C1, C2, C3, out);
+    if (rc) { ev2h_set_error("ev2h_tile_geometry: unsupported chain %d-%d-%d", C1, C2, C3); return rc; }
+    return ev2h_gemm_tile_geometry(planes, out + 6);
+}
+
 extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d && d->T && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
     EV2H_CHECK_ARG((d->nn_idx != nullptr) == (d->nn_w != nullptr));
@@ -590,6 +620,7 @@ extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
     p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
     p.ncols = ncols; p.relu_out = d->no_relu_out ? 0 : 1; p.out_cm = d->out_cm;
+    p.out_cm_stride = d->out_cm_stride ? d->out_cm_stride : (size_t)ncols * d->N;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * p.S, SAB_WAVES);
     if (d->precision == EV2H_PREC_F16X2) {

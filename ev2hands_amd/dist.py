@@ -89,3 +89,31 @@ def all_gather_outputs(out: dict, N: int, group=None, global_batch: int | None =
     dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
     rows = torch.cat([full[r * big:r * big + sizes[r]] for r in range(world)], 0)
     return unpack_outputs(rows, N)
+
+
+class GatherBuffer:
+    """This rank's persistent all-gather buffer: float32 [world * big, packed_width(N)], big = the largest shard.
+
+    `rows()` is the slice the local forward writes straight into (TEHNet.forward(..., rows=buf.rows()): ev2h_outputs' window
+    strides), `gather()` runs ONE in-place all_gather_into_tensor (the send buffer is this rank's slice of the receive buffer,
+    which RCCL recognises as its in-place form) and returns the global predictions as views of the buffer -- no packing copy, no
+    concatenation, no per-step allocation.  Unequal shards: a short shard leaves the tail of its slice unused and `gather()`
+    trims it (the only case that copies)."""
+
+    def __init__(self, N: int, global_batch: int, device, group=None):
+        self.group, self.N = group, N
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
+        self.big = max(self.sizes)
+        self.full = torch.zeros(self.world * self.big, packed_width(N), dtype=torch.float32, device=device)
+
+    def rows(self) -> torch.Tensor:
+        lo = self.rank * self.big
+        return self.full[lo:lo + self.sizes[self.rank]]
+
+    def gather(self) -> dict:
+        lo = self.rank * self.big
+        dist.all_gather_into_tensor(self.full, self.full[lo:lo + self.big], group=self.group)
+        if min(self.sizes) == self.big:
+            return unpack_outputs(self.full, self.N)
+        return unpack_outputs(torch.cat([self.full[r * self.big:r * self.big + self.sizes[r]] for r in range(self.world)], 0), self.N)

@@ -100,7 +100,7 @@ class ManoHand:
         joints = torch.empty(B, 21, 3, device=self.device, dtype=torch.float32)
         c = self.consts()
         L = _lib.lib()
-        _lib.check(L.ev2h_mano(C.byref(c), prm.data_ptr(), prm.shape[1], B, verts.data_ptr(), joints.data_ptr(),
+        _lib.check(L.ev2h_mano(C.byref(c), prm.data_ptr(), prm.shape[1], B, verts.data_ptr(), 0, joints.data_ptr(), 0,
                                _lib.stream_handle()), "ev2h_mano")
         return ManoOutput(verts, joints)
 
@@ -121,20 +121,44 @@ class _Stub:
 
 
 class _ManoUnpickler(pickle.Unpickler):
+    """MANO_*.pkl are Python-2 protocol-2 pickles that reference `chumpy.ch.Ch` (and other chumpy classes) and
+    `scipy.sparse.csc.csc_matrix` as scipy laid it out in 2017.  Neither package is needed to get the arrays out: both families
+    are replaced by stubs that keep the pickled state (so the reader does not depend on chumpy being installed or on how the
+    installed scipy restores a matrix pickled by an old one)."""
+
     def find_class(self, module, name):
-        if module.startswith("chumpy"):
-            return type(name, (_Stub,), {})
+        if module.startswith("chumpy") or module.startswith("scipy.sparse"):
+            return type(name, (_Stub,), {"_pickled_module": module})
         return super().find_class(module, name)
 
 
 def _as_array(x) -> np.ndarray:
-    """ndarray out of a plain array, a scipy sparse matrix or a chumpy stub (its state holds 'x')."""
+    """ndarray out of a plain array, a scipy sparse matrix (live, or a stub holding its pickled data / indices / indptr / shape)
+    or a chumpy stub (its state holds 'x')."""
     if isinstance(x, np.ndarray):
         return x
     if hasattr(x, "toarray"):
         return np.asarray(x.toarray())
     st = getattr(x, "_state", None)
     if isinstance(st, dict):
+        if "indptr" in st and "indices" in st and "data" in st:                  # compressed sparse column / row matrix
+            shape = st.get("_shape", st.get("shape"))
+            if shape is None:
+                raise TypeError("sparse matrix state without a shape")
+            rows, cols = int(shape[0]), int(shape[1])
+            data, indices, indptr = (np.asarray(st[k]) for k in ("data", "indices", "indptr"))
+            by_column = type(x).__name__.startswith("csc")
+            if not by_column and not type(x).__name__.startswith("csr"):
+                raise TypeError(f"unsupported sparse format {type(x).__name__}")
+            if indptr.shape[0] != (cols if by_column else rows) + 1:
+                raise TypeError("sparse matrix state is inconsistent (indptr length)")
+            out = np.zeros((rows, cols), dtype=np.float64)
+            major = np.repeat(np.arange(indptr.shape[0] - 1), np.diff(indptr))
+            if by_column:
+                np.add.at(out, (indices, major), data)                           # duplicates sum, as scipy's toarray() does
+            else:
+                np.add.at(out, (major, indices), data)
+            return out
         for key in ("x", "a"):
             if key in st:
                 return _as_array(st[key])

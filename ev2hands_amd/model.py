@@ -97,22 +97,39 @@ class TEHNet(nn.Module):
         # per-window range scaling, any checkpoint / input magnitude), "bf16x3" (fp32-class three-plane bf16 split), "f32"
         # (exact fp32 MFMA), "bf16" (reduced precision)
         self.precision = os.getenv("EV2H_PRECISION", "f16x2")
+        # exact power-of-two equalisation of the hidden channels when the checkpoint is packed (pack.py: equalize_channels): the
+        # fp32 function is unchanged bit for bit, the 16-bit planes see well-conditioned operands whatever the BatchNorm scales are
+        self.equalize = True
         self.left_query_conv = _query_conv()
         self.right_query_conv = _query_conv()
         self._packed = None
         self._packed_key = None
+        self._key_tensors = None
+        self._faces_cache = {}
         self._ws = None
         self.fps_init = None          # optional override: list of four [B] int64 tensors for the next forward
 
     # -- weight packing (re-done whenever parameters/buffers change or move) ---------------------
     def _pack_key(self):
-        ts = list(self.parameters()) + list(self.buffers())
+        # (walking the module tree costs ~2 ms per call -- more than a B = 1 forward; the tensor list is cached and dropped
+        # whenever nn.Module machinery may have replaced tensor objects: _apply (.to / .cuda / .float) and load_state_dict)
+        ts = self._key_tensors
+        if ts is None:
+            ts = self._key_tensors = list(self.parameters()) + list(self.buffers())
         return (str(ts[0].device), tuple((t.data_ptr(), t._version) for t in ts))
 
+    def _apply(self, fn, *args, **kwargs):
+        self._key_tensors = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._key_tensors = None
+        return super().load_state_dict(*args, **kwargs)
+
     def packed(self, device) -> PackedWeights:
-        key = (str(device), self.precision, self._pack_key())
+        key = (str(device), self.precision, self.equalize, self._pack_key())
         if self._packed is None or self._packed_key != key:
-            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, self.precision)
+            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, self.precision, equalize=self.equalize)
             self._packed_key = key
         return self._packed
 
@@ -140,9 +157,12 @@ class TEHNet(nn.Module):
         if self.mhlnes and not xyz.is_contiguous():
             raise RuntimeError("MHLNES=1 writes channel 2 in place and needs a contiguous input")
 
-    def _enqueue(self, x, init_dev, mano_hands):
+    def _enqueue(self, x, init_dev, mano_hands, rows=None, ws=None):
         """One ev2h_forward on the current stream: device work only (no host synchronisation, no host->device copy), so that it
-        can run under stream capture.  x [B,C,N] contiguous float32, init_dev [4,B] int64 on the device."""
+        can run under stream capture.  x [B,C,N] contiguous float32, init_dev [4,B] int64 on the device.
+        rows: optional float32 [B, >= dist.packed_width(N)] matrix (row stride = its second dimension) that receives every window's
+        predictions side by side -- ev2h_outputs' window strides; the returned tensors are then views of it.  ws: workspace to use
+        instead of the net's shared one (captured graphs own theirs)."""
         device = x.device
         B, Cin, N = x.shape
         L = _lib.lib()
@@ -154,18 +174,37 @@ class TEHNet(nn.Module):
         consts = {s: (C.byref(mano_hands[s].consts()) if native[s] else None) for s in ("left", "right")}
 
         f32 = dict(device=device, dtype=torch.float32)
-        logits = torch.empty(B, 4, N, **f32)
-        params = [torch.empty(B, synth.N_MANO_OUT, **f32) for _ in range(2)]
-        verts = [torch.empty(B, synth.MANO_NV, 3, **f32) for _ in range(2)]
-        joints = [torch.empty(B, 21, 3, **f32) for _ in range(2)]
         out = _lib.Outputs()
+        NP, NVF = synth.N_MANO_OUT, synth.MANO_NV * 3
+        if rows is None:
+            logits = torch.empty(B, 4, N, **f32)
+            params = [torch.empty(B, NP, **f32) for _ in range(2)]
+            verts = [torch.empty(B, synth.MANO_NV, 3, **f32) for _ in range(2)]
+            joints = [torch.empty(B, 21, 3, **f32) for _ in range(2)]
+        else:
+            W = rows.shape[1] if rows.dim() == 2 else 0
+            per_hand = NP + NVF + 63
+            if (rows.dim() != 2 or rows.shape[0] != B or W < 4 * N + 2 * per_hand or rows.dtype != torch.float32 or rows.device != device
+                    or rows.stride() != (W, 1)):
+                raise RuntimeError(f"rows must be a float32 [B={B}, >= {4 * N + 2 * per_hand}] row-major matrix on {device}")
+            logits = rows[:, :4 * N].view(B, 4, N)
+            params, verts, joints = [], [], []
+            for h in range(2):
+                o = 4 * N + h * per_hand
+                params.append(rows[:, o:o + NP])
+                verts.append(rows[:, o + NP:o + NP + NVF].view(B, synth.MANO_NV, 3))
+                joints.append(rows[:, o + NP + NVF:o + per_hand].view(B, 21, 3))
+            out.logits_stride = out.params_stride = out.vertices_stride = out.joints_stride = W
         out.class_logits = logits.data_ptr()
         for h in range(2):
             out.params[h] = params[h].data_ptr()
             out.vertices[h] = verts[h].data_ptr()
             out.joints[h] = joints[h].data_ptr()
         nbytes = L.ev2h_workspace_bytes(B, N)
-        ws = self.workspace(nbytes, device)
+        if ws is None:
+            ws = self.workspace(nbytes, device)
+        elif ws.numel() < nbytes or ws.device != device:
+            raise RuntimeError("workspace too small or on another device")
         with torch.cuda.device(device):
             _lib.check(L.ev2h_forward(C.byref(pw.struct), consts["left"], consts["right"], x.data_ptr(), B, Cin, N, self.mhlnes,
                                       init_dev.data_ptr(), C.byref(out), ws.data_ptr(), nbytes, _lib.stream_handle()),
@@ -182,11 +221,18 @@ class TEHNet(nn.Module):
                 d = {k: v.to(hd) for k, v in d.items()}
                 o = mano_hands[side](**d)
                 d = {"vertices": o.vertices, "j3d": o.joints, **d}
+                if rows is not None:                                         # a foreign hand model's results join the row as well
+                    verts[h].copy_(o.vertices.to(device))
+                    joints[h].copy_(o.joints.to(device))
             res[side] = d
         self._last_shape = (B, N)
+        self._last_ws = ws
         return res
 
-    def forward(self, xyz, mano_hands):
+    def forward(self, xyz, mano_hands, rows=None):
+        """TEHNet.py:168-197.  rows (extension, optional): float32 [B, >= 4N + 2 * 2419] matrix that receives each window's
+        predictions as one row ([4N logits | left 22 params, 778x3 vertices, 21x3 joints | right ...], ev2hands_amd/dist.py);
+        the returned tensors are then views of it -- the multi-GPU path passes its slice of the all-gather buffer."""
         self._check_input(xyz)
         device = xyz.device
         B, Cin, N = xyz.shape
@@ -194,10 +240,21 @@ class TEHNet(nn.Module):
         inits = self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N)
         self.fps_init = None
         init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
-        res = self._enqueue(x, init_dev, mano_hands)
+        res = self._enqueue(x, init_dev, mano_hands, rows=rows)
         for side in ("left", "right"):
-            res[side]["faces"] = np.tile(mano_hands[side].faces, (B, 1, 1))      # eval only (TEHNet.py:109-110)
+            res[side]["faces"] = self._tiled_faces(mano_hands[side], B)          # eval only (TEHNet.py:109-110)
         return res
+
+    def _tiled_faces(self, hand, B: int):
+        """np.tile(faces, (B, 1, 1)) as TEHNet.py:110 returns it, built once per (hand model, B): at B = 256 the two tilings are
+        19 MB of host copies per forward."""
+        key = (id(hand), id(hand.faces), B)
+        hit = self._faces_cache.get(key)
+        if hit is None:
+            if len(self._faces_cache) > 8:
+                self._faces_cache.clear()
+            hit = self._faces_cache[key] = (np.tile(hand.faces, (B, 1, 1)), hand, hand.faces)
+        return hit[0]
 
     def capture(self, xyz, mano_hands, fps_init=None) -> "CapturedForward":
         """Capture one forward for inputs of xyz's shape into a hipGraph (torch.cuda.CUDAGraph: stream capture of the kernel
@@ -215,11 +272,12 @@ class TEHNet(nn.Module):
         B, N = self._last_shape
         L = _lib.lib()
         cnt = C.c_size_t(0)
-        p = L.ev2h_workspace_buffer(self._ws.data_ptr(), B, N, name.encode(), C.byref(cnt))
+        ws = self._last_ws
+        p = L.ev2h_workspace_buffer(ws.data_ptr(), B, N, name.encode(), C.byref(cnt))
         if not p:
             raise KeyError(name)
-        off = p - self._ws.data_ptr()
-        return self._ws[off:off + cnt.value * 4].view(dtype).clone()
+        off = p - ws.data_ptr()
+        return ws[off:off + cnt.value * 4].view(dtype).clone()
 
 
 class CapturedForward:
@@ -232,12 +290,21 @@ class CapturedForward:
         self.x = xyz.detach().clone().contiguous()
         inits = fps_init if fps_init is not None else net.draw_fps_init(B, N)
         self.init = torch.stack([t.to(torch.long) for t in inits]).to(device).contiguous()
+        # The graph bakes in device addresses: the workspace and the packed weights.  Both are owned HERE -- the net's shared
+        # workspace is re-allocated by a later, larger eager forward, and the packed weights are dropped when the parameters or
+        # the precision change (a replay would then read and write freed memory).
+        self._ws = torch.empty(_lib.lib().ev2h_workspace_bytes(B, N), dtype=torch.uint8, device=device)
+        self._pw = net.packed(device)
+        self._key = (net.precision, net.equalize, net._pack_key())
+        for s in ("left", "right"):
+            mano_hands[s].consts()
+        self._mano_keep = {s: (mano_hands[s]._keep, mano_hands[s].shapedirs._version) for s in ("left", "right")}    # MANO constant tensors
         with torch.no_grad():
-            net._enqueue(self.x, self.init, mano_hands)      # warm-up outside the capture: per-kernel attributes, occupancy queries
+            net._enqueue(self.x, self.init, mano_hands, ws=self._ws)   # warm-up outside the capture: kernel attributes, occupancy queries
             torch.cuda.synchronize(device)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.out = net._enqueue(self.x, self.init, mano_hands)
+                self.out = net._enqueue(self.x, self.init, mano_hands, ws=self._ws)
         self.faces = {s: np.tile(mano_hands[s].faces, (B, 1, 1)) for s in ("left", "right")}
         for s in ("left", "right"):
             self.out[s]["faces"] = self.faces[s]
@@ -247,6 +314,11 @@ class CapturedForward:
     def replay(self, xyz=None, fps_init=None) -> dict:
         """Run the captured forward (optionally on new inputs of the captured shape).  The returned tensors are the graph's static
         outputs: they are overwritten by the next replay."""
+        if (self.net.precision, self.net.equalize, self.net._pack_key()) != self._key:
+            raise RuntimeError("the network's parameters, device or precision changed since this forward was captured: the graph "
+                               "holds the old packed weights -- capture again")
+        if any(self.hands[s].shapedirs._version != self._mano_keep[s][1] for s in ("left", "right")):
+            raise RuntimeError("a hand model's shapedirs changed since this forward was captured -- capture again")
         if xyz is not None:
             if tuple(xyz.shape) != tuple(self.x.shape):
                 raise RuntimeError(f"captured for input {tuple(self.x.shape)}, got {tuple(xyz.shape)}")
@@ -287,6 +359,14 @@ class TEHNetWrapper:
 
     def load_state_dict(self, params, *args, **kwargs):
         stripped = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in params.items()}
+        # The input width is fixed at construction by the environment (TEHNet.py:122: 4 channels, 5 with ERPC=1); a checkpoint
+        # trained with the other setting fails strict loading with a size mismatch buried in a long message -- say what it is.
+        w = stripped.get("sa1.conv_blocks.0.0.weight")
+        if w is not None and w.dim() == 4 and int(w.shape[1]) - 3 != self.net.in_channels:
+            c = int(w.shape[1]) - 3
+            raise RuntimeError(f"checkpoint expects {c} input channels (trained with ERPC={int(c == 5)}) but this model was built for "
+                               f"{self.net.in_channels} (ERPC={os.getenv('ERPC', '0')} when it was constructed): set ERPC={int(c == 5)} "
+                               f"before creating TEHNetWrapper (the reference reads it at construction, TEHNet.py:122)")
         return self.net.load_state_dict(stripped, *args, **kwargs)
 
     def parameters(self):

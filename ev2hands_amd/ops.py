@@ -243,15 +243,17 @@ def row_chain(X: torch.Tensor, W2, b2, W3, b3, precision: str = "f16x2", relu_ou
     return out, out_cm
 
 
-def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor, hf_amax: torch.Tensor | None = None):
+def attention(logits_pm: torch.Tensor, query_pm: torch.Tensor, value_pm: torch.Tensor, hf_amax: torch.Tensor | None = None,
+              value_unscale: torch.Tensor | None = None):
     """TEHNet.py:13-27 for both hands.  logits_pm [B,N,4], query_pm [2,B,N,256], value_pm [B,N,256]
-    -> (sim [B,2,4,256], hf8 [2,B,N,8]).  hf_amax: optional range records [2,B] of the context features."""
+    -> (sim [B,2,4,256], hf8 [2,B,N,8]).  hf_amax: optional range records [2,B] of the context features;
+    value_unscale: optional [256] per-channel factors of value (ev2h_attn_context)."""
     B, N, _ = logits_pm.shape
     sim = torch.empty(B, 2, 4, 256, device=logits_pm.device, dtype=torch.float32)
     hf8 = torch.empty(2, B, N, 8, device=logits_pm.device, dtype=torch.float32)
     L = _lib.lib()
     _lib.check(L.ev2h_attn_sim(logits_pm.data_ptr(), query_pm.data_ptr(), 256, B * N * 256, B, N, sim.data_ptr(), _st()), "sim")
-    _lib.check(L.ev2h_attn_context(sim.data_ptr(), value_pm.data_ptr(), 256, B, N, hf8.data_ptr(), _lib.ptr(hf_amax), B, _st()), "ctx")
+    _lib.check(L.ev2h_attn_context(sim.data_ptr(), value_pm.data_ptr(), 256, B, N, hf8.data_ptr(), _lib.ptr(hf_amax), B, _lib.ptr(value_unscale), _st()), "ctx")
     return sim, hf8
 
 

@@ -103,6 +103,14 @@ def sa_bf16_geometry(C2: int):
     return T2, 32 * (T2 - 1) + 16 * m_last
 
 
+def kernel_geometry(C1: int, C2: int, C3: int, ns: int) -> dict:
+    """Tile-image geometry of a chain as the KERNELS define it (ev2h_tile_geometry: csrc/sa_mlp_bf16.hip SaBCfg, csrc/gemm_bf16.hip
+    GBCfg) -- the one source of truth the image builders below are asserted against."""
+    out = (C.c_int * 8)()
+    _lib.check(_lib.lib().ev2h_tile_geometry(C1, C2, C3, ns, out), "ev2h_tile_geometry")
+    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK"), out))
+
+
 def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     """Byte images of the LDS weight tiles of sa_mlp_max_bf16_kernel (see SaBCfg in csrc/sa_mlp_bf16.hip).
     W2 [C2, C1], W3 [C3, C2] folded fp32 weights.  Returns (W2s, W3s, u2, u3): uint8 images of W2 / u2 and W3 / u3 and the
@@ -135,6 +143,10 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     for s_ in range(ns):
         blk = p3[s_].view(np.uint8).reshape(C3 // 32, 32, C2P * 2)
         img3[:, :, s_ * C2P * 2:(s_ + 1) * C2P * 2] = blk
+    g = kernel_geometry(C1, C2, C3, ns)
+    mine = {"T2": T2, "C2P": C2P, "RS2": rs2, "RS3": rs3, "TB2": img2[0].size, "TB3": img3[0].size}
+    if any(g[k] != v for k, v in mine.items()):
+        raise _lib.Ev2hError(f"tile geometry of chain {C1}-{C2}-{C3} (planes {ns}): pack.py builds {mine}, the kernels expect {g}")
     return img2.reshape(-1), img3.reshape(-1), u2, u3
 
 
@@ -152,6 +164,9 @@ def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS):
     Wp = _pad(W, tn * rows, nk * 32)
     planes = split_bf16_planes(Wp, ns)
     rs = ns * 64 + 16
+    g = kernel_geometry(128, 128, 256, ns)
+    if (g["GEMM_RS"], g["GEMM_BK"]) != (rs, 32):
+        raise _lib.Ev2hError(f"dense W image geometry: pack.py builds rows of {rs} B x 32 k, the kernels expect {g['GEMM_RS']} B x {g['GEMM_BK']} k")
     img = np.zeros((tn, nk, rows, rs), dtype=np.uint8)
     for s_ in range(ns):
         blk = planes[s_].reshape(tn, rows, nk, 32).transpose(0, 2, 1, 3)         # [tn, nk, rows, 32] uint16
@@ -159,10 +174,159 @@ def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS):
     return img.reshape(-1), u
 
 
+
+# ------------------------------------------------------------------------------------ folded checkpoint + channel equalisation
+def fold_checkpoint(sd: dict) -> dict:
+    """Every layer of the path with eval-BN folded (float64): name -> {"W": [O, I] (k=3 convolutions: [O, I, 3]), "b": [O],
+    "ps"/"pt": post-ReLU BatchNorm scale / shift [O] or None}, input columns in the CHECKPOINT's order."""
+    F = {}
+
+    def msg(prefix, nbranch):
+        for i in range(nbranch):
+            for j in range(3):
+                W, b = _fold(sd, f"{prefix}.conv_blocks.{i}.{j}", f"{prefix}.bn_blocks.{i}.{j}")
+                F[f"{prefix}.{i}.{j}"] = {"W": W[:, :, 0, 0], "b": b, "ps": None, "pt": None}
+
+    def stack(prefix, n):
+        for k in range(n):
+            W, b = _fold(sd, f"{prefix}.mlp_convs.{k}", f"{prefix}.mlp_bns.{k}")
+            F[f"{prefix}.{k}"] = {"W": W.reshape(W.shape[0], W.shape[1]), "b": b, "ps": None, "pt": None}
+
+    def post(name, pc, pb):
+        W = _np(sd[pc + ".weight"])
+        a, be = _bn_affine(sd, pb)
+        F[name] = {"W": W[:, :, 0] if (W.ndim == 3 and W.shape[2] == 1) else W, "b": _np(sd[pc + ".bias"]), "ps": a, "pt": be}
+
+    def plain(name, pc):
+        W = _np(sd[pc + ".weight"])
+        F[name] = {"W": W[:, :, 0] if W.ndim == 3 else W, "b": _np(sd[pc + ".bias"]), "ps": None, "pt": None}
+
+    msg("sa1", 3)
+    msg("sa2", 2)
+    stack("sa3", 3)
+    stack("fp3", 2)
+    stack("fp2", 2)
+    stack("fp1", 3)
+    post("cls0", "classifier.0", "classifier.2")
+    plain("cls4", "classifier.4")
+    for side in ("left", "right"):
+        q = f"{side}_query_conv"
+        post(q + ".0", q + ".0", q + ".2")                               # W [256, 256, 3]
+        W4, b4 = _fold(sd, q + ".4", q + ".5")
+        F[q + ".4"] = {"W": W4, "b": b4, "ps": None, "pt": None}
+        p = f"{side}_mano_regressor"
+        msg(p + ".sa1", 2)
+        stack(p + ".sa2", 2)
+        post(p + ".head0", p + ".mano_regressor.0", p + ".mano_regressor.2")
+        plain(p + ".head4", p + ".mano_regressor.4")
+    return F
+
+
+def hidden_tensors():
+    """The hidden tensors of the path as (name, producers, consumers): producers = [(layer, "rows" | "post")] in channel order
+    (a concatenation has several), consumers = [(layer, first input column)].  Every producer ends in a ReLU (positively
+    homogeneous) or a post-ReLU affine, and everything between producer and consumer (gather, max-pool, 3-NN interpolation,
+    concatenation, broadcast) acts per channel -- so channel c may be multiplied by any e_c > 0 at the producer and divided at the
+    consumers without changing the network function.  Column offsets: pointnet2_utils.py:155,248,261,307, TEHNet.py:179-195."""
+    T = []
+
+    def msg(p, nb, consumers):
+        outs = []
+        for i in range(nb):
+            T.append((f"{p}.{i}.h1", [(f"{p}.{i}.0", "rows")], [(f"{p}.{i}.1", 0)]))
+            T.append((f"{p}.{i}.h2", [(f"{p}.{i}.1", "rows")], [(f"{p}.{i}.2", 0)]))
+            outs.append((f"{p}.{i}.2", "rows"))
+        T.append((p + ".out", outs, consumers))
+
+    msg("sa1", 3, [("sa2.0.0", 0), ("sa2.1.0", 0), ("fp2.0", 0)])
+    msg("sa2", 2, [("sa3.0", 3), ("fp3.0", 0)])
+    T.append(("sa3.h1", [("sa3.0", "rows")], [("sa3.1", 0)]))
+    T.append(("sa3.h2", [("sa3.1", "rows")], [("sa3.2", 0)]))
+    T.append(("l3", [("sa3.2", "rows")], [("fp3.0", 512)]))
+    T.append(("fp3.h", [("fp3.0", "rows")], [("fp3.1", 0)]))
+    T.append(("fp3.out", [("fp3.1", "rows")], [("fp2.0", 320)]))
+    T.append(("fp2.h", [("fp2.0", "rows")], [("fp2.1", 0)]))
+    T.append(("fp2.out", [("fp2.1", "rows")], [("fp1.0", 0)]))
+    T.append(("fp1.h1", [("fp1.0", "rows")], [("fp1.1", 0)]))
+    T.append(("fp1.h2", [("fp1.1", "rows")], [("fp1.2", 0)]))
+    # l0 also is the attention's `value` (TEHNet.py:20-26: context = sim @ value, linear in value): that consumer divides by e_c
+    # through ev2h_weights.l0_unscale
+    T.append(("l0", [("fp1.2", "rows")], [("cls0", 0), ("left_query_conv.0", 0), ("right_query_conv.0", 0)]))
+    T.append(("cls.h", [("cls0", "post")], [("cls4", 0)]))
+    for side in ("left", "right"):
+        q, p = f"{side}_query_conv", f"{side}_mano_regressor"
+        T.append((q + ".h", [(q + ".0", "post")], [(q + ".4", 0)]))
+        msg(p + ".sa1", 2, [(p + ".sa2.0", 3)])
+        T.append((p + ".sa2.h", [(p + ".sa2.0", "rows")], [(p + ".sa2.1", 0)]))
+        T.append((p + ".sa2.out", [(p + ".sa2.1", "rows")], [(p + ".head0", 0)]))
+        T.append((p + ".fc1", [(p + ".head0", "post")], [(p + ".head4", 0)]))
+    return T
+
+
+def equalize_channels(F: dict, sweeps: int = 3) -> dict:
+    """Cross-layer channel equalisation by exact powers of two, in place; returns name -> e [channels] (the accumulated factor
+    of every hidden tensor).
+
+    Why: the f16x2 arithmetic scales every tensor by ONE power of two per window and every weight matrix by one per matrix
+    (csrc/planes.hpp, plane_unscale); a value then keeps its 22 bits only down to 2^-17 of the tensor's maximum.  A checkpoint
+    may distribute magnitude between a hidden channel and the weights that read it in any way (BatchNorm scales gamma_c of a
+    trained model differ by orders of magnitude; gamma_c -> a gamma_c with the consumers' columns / a is the same network):
+    with channels 2^16 apart the small channels and, symmetrically, the small weight columns lost most of their low planes
+    (measured 2.7e-3 instead of 3e-7).  This pass picks the representative of that equivalence class that the split arithmetic
+    likes: e_c = 2^round(log2(sqrt(column norm of the consumers / row norm of the producer))) balances what the channel carries
+    against what multiplies it (Nagel et al., data-free quantisation, 2019, restricted to powers of two so that every product
+    and every partial sum changes by an exact power of two: the fp32 result of every layer is bit-identical, only the 16-bit
+    planes see better-conditioned operands).  No calibration data is needed and nothing runs per forward."""
+    acc = {}
+    for _ in range(sweeps):
+        for name, producers, consumers in hidden_tensors():
+            r = []
+            for layer, kind in producers:
+                L = F[layer]
+                W2 = L["W"].reshape(L["W"].shape[0], -1)
+                rn = np.sqrt((W2 ** 2).sum(1) + L["b"] ** 2)
+                r.append(np.abs(L["ps"]) * rn + np.abs(L["pt"]) if kind == "post" else rn)
+            r = np.concatenate(r)
+            n = r.shape[0]
+            om = np.zeros(n)
+            for layer, off in consumers:
+                W = F[layer]["W"]
+                cols = W[:, off:off + n]
+                cn = np.sqrt((cols ** 2).sum(axis=tuple(i for i in range(cols.ndim) if i != 1)))
+                rms = np.sqrt((cn ** 2).mean())
+                if rms > 0:
+                    om += (cn / rms) ** 2
+            om = np.sqrt(om)
+            ok = (r > 0) & (om > 0) & np.isfinite(r) & np.isfinite(om)
+            lg = np.zeros(n)
+            lg[ok] = 0.5 * (np.log2(om[ok]) - np.log2(r[ok]))
+            if ok.any():
+                lg[ok] -= np.median(lg[ok])                  # keep the tensor's overall magnitude where the checkpoint put it
+            e = np.exp2(np.clip(np.round(lg), -40, 40))
+            o = 0
+            for layer, kind in producers:
+                L = F[layer]
+                k = L["W"].shape[0]
+                ek = e[o:o + k]
+                if kind == "post":
+                    L["ps"] = L["ps"] * ek
+                    L["pt"] = L["pt"] * ek
+                else:
+                    L["W"] = L["W"] * ek.reshape((-1,) + (1,) * (L["W"].ndim - 1))
+                    L["b"] = L["b"] * ek
+                o += k
+            for layer, off in consumers:
+                W = F[layer]["W"].copy()
+                W[:, off:off + n] = W[:, off:off + n] / e.reshape((1, n) + (1,) * (W.ndim - 2))
+                F[layer]["W"] = W
+            acc[name] = acc.get(name, np.ones(n)) * e
+    return acc
+
+
 class PackedWeights:
     """Owns the device tensors and the ev2h_weights struct that points at them."""
 
-    def __init__(self, sd: dict, device, in_channels: int, precision: str = "f32"):
+    def __init__(self, sd: dict, device, in_channels: int, precision: str = "f32", equalize: bool = True):
         self.device = torch.device(device)
         self.in_channels = in_channels
         self.precision = precision
@@ -172,56 +336,55 @@ class PackedWeights:
         self.struct = _lib.Weights()
         w = self.struct
         w.precision = _lib.PREC[precision]
-        self._sa_module(w.sa1, sd, "sa1", in_channels, 8, synth.SA1_NPOINT, synth.SA1_RADII, synth.SA1_NSAMPLE)
-        self._sa_module(w.sa2, sd, "sa2", 320, 320, synth.SA2_NPOINT, synth.SA2_RADII, synth.SA2_NSAMPLE)
+        F = fold_checkpoint(sd)
+        # exact power-of-two channel equalisation (equalize_channels): applied in EVERY precision mode, so that all modes run the
+        # same network representation (the exact-fp32 results do not change by a bit)
+        self.equalization = equalize_channels(F) if equalize else {}
+        self._sa_module(w.sa1, F, "sa1", in_channels, 8, synth.SA1_NPOINT, synth.SA1_RADII, synth.SA1_NSAMPLE)
+        self._sa_module(w.sa2, F, "sa2", 320, 320, synth.SA2_NPOINT, synth.SA2_RADII, synth.SA2_NSAMPLE)
         for h, side in enumerate(("left", "right")):
             p = f"{side}_mano_regressor"
-            self._sa_module(w.mano_sa1[h], sd, p + ".sa1", 4, 8, synth.MANO_SA1_NPOINT, synth.MANO_SA1_RADII,
+            self._sa_module(w.mano_sa1[h], F, p + ".sa1", 4, 8, synth.MANO_SA1_NPOINT, synth.MANO_SA1_RADII,
                             synth.MANO_SA1_NSAMPLE)
-            self._group_all(w.mano_sa2[h], sd, p + ".sa2", 2)
-            W, b = _np(sd[p + ".mano_regressor.0.weight"]), _np(sd[p + ".mano_regressor.0.bias"])
-            a, be = _bn_affine(sd, p + ".mano_regressor.2")
-            self._dense(w.head0[h], p + ".head0", W, b, a, be)
-            self._dense(w.head4[h], p + ".head4", _np(sd[p + ".mano_regressor.4.weight"]),
-                        _np(sd[p + ".mano_regressor.4.bias"]))
-        self._group_all(w.sa3, sd, "sa3", 3)
+            self._group_all(w.mano_sa2[h], F, p + ".sa2", 2)
+            L0, L4 = F[p + ".head0"], F[p + ".head4"]
+            self._dense(w.head0[h], p + ".head0", L0["W"], L0["b"], L0["ps"], L0["pt"])
+            self._dense(w.head4[h], p + ".head4", L4["W"], L4["b"])
+        self._group_all(w.sa3, F, "sa3", 3)
         # fp3: 1536 = 512 skip (l2_points) + 1024 broadcast (l3_points), pointnet2_utils.py:293-294,307
-        W, b = _fold(sd, "fp3.mlp_convs.0", "fp3.mlp_bns.0")
-        W = W[:, :, 0]
+        W, b = F["fp3.0"]["W"], F["fp3.0"]["b"]
         self._dense(w.fp3_skip, "fp3.skip", W[:, :512], None)
         self._dense(w.fp3_bcast, "fp3.bcast", W[:, 512:], b)
-        W, b = _fold(sd, "fp3.mlp_convs.1", "fp3.mlp_bns.1")
-        self._dense(w.fp3_1, "fp3.1", W[:, :, 0], b)
+        self._dense(w.fp3_1, "fp3.1", F["fp3.1"]["W"], F["fp3.1"]["b"])
         for k in range(2):
-            W, b = _fold(sd, f"fp2.mlp_convs.{k}", f"fp2.mlp_bns.{k}")
-            self._dense(w.fp2[k], f"fp2.{k}", W[:, :, 0], b)
+            self._dense(w.fp2[k], f"fp2.{k}", F[f"fp2.{k}"]["W"], F[f"fp2.{k}"]["b"])
         for k in range(3):
-            W, b = _fold(sd, f"fp1.mlp_convs.{k}", f"fp1.mlp_bns.{k}")
-            self._dense(w.fp1[k], f"fp1.{k}", W[:, :, 0], b)
+            self._dense(w.fp1[k], f"fp1.{k}", F[f"fp1.{k}"]["W"], F[f"fp1.{k}"]["b"])
         if self.ns:
-            self._fp_module(w.fp1m, sd, "fp1")
-        a, be = _bn_affine(sd, "classifier.2")
-        self._dense(w.cls0, "cls0", _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be)
-        self._dense(w.cls4, "cls4", _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
+            self._fp_module(w.fp1m, F, "fp1")
+        c0, c4 = F["cls0"], F["cls4"]
+        self._dense(w.cls0, "cls0", c0["W"], c0["b"], c0["ps"], c0["pt"])
+        self._dense(w.cls4, "cls4", c4["W"], c4["b"])
         if self.ns:
-            self._cls_module(w.clsm, _np(sd["classifier.0.weight"])[:, :, 0], _np(sd["classifier.0.bias"]), a, be,
-                             _np(sd["classifier.4.weight"])[:, :, 0], _np(sd["classifier.4.bias"]))
+            self._cls_module(w.clsm, c0["W"], c0["b"], c0["ps"], c0["pt"], c4["W"], c4["b"])
         # query convs: tap-major [O][3*I]; both hands' first conv stacked along O
         W0, b0, a0, be0 = [], [], [], []
         for h, side in enumerate(("left", "right")):
             p = f"{side}_query_conv"
-            W = _np(sd[p + ".0.weight"])                                  # [O, I, 3]
-            W0.append(np.ascontiguousarray(W.transpose(0, 2, 1)).reshape(W.shape[0], -1))
-            b0.append(_np(sd[p + ".0.bias"]))
-            a, be = _bn_affine(sd, p + ".2")
-            a0.append(a)
-            be0.append(be)
-            W4, b4 = _fold(sd, p + ".4", p + ".5")
+            L = F[p + ".0"]                                                # W [O, I, 3]
+            W0.append(np.ascontiguousarray(L["W"].transpose(0, 2, 1)).reshape(L["W"].shape[0], -1))
+            b0.append(L["b"])
+            a0.append(L["ps"])
+            be0.append(L["pt"])
+            W4, b4 = F[p + ".4"]["W"], F[p + ".4"]["b"]
             W4 = np.ascontiguousarray(W4.transpose(0, 2, 1)).reshape(W4.shape[0], -1)
             self._dense(w.qconv4[h], p + ".4", W4, b4, K=256)
             w.qconv4T[h] = self._dev(p + ".4.WT", np.ascontiguousarray(W4.T))        # [768, 256]: ev2h_attn_sim_folded
         self._dense(w.qconv0, "qconv0", np.concatenate(W0, 0), np.concatenate(b0), np.concatenate(a0),
                     np.concatenate(be0), K=256)
+        # the attention's `value` is l0 itself (TEHNet.py:20-26): its channels are divided by their equalisation factor there
+        e_l0 = self.equalization.get("l0")
+        w.l0_unscale = self._dev("l0.unscale", 1.0 / e_l0) if e_l0 is not None and np.any(e_l0 != 1.0) else None
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, name: str, a: np.ndarray) -> int:
@@ -251,12 +414,11 @@ class PackedWeights:
         else:
             d.w_unscale = plane_unscale(W, self.ns)        # the kernel splits W / w_unscale on the fly
 
-    def _group_all(self, arr, sd, prefix, nlayers):
+    def _group_all(self, arr, F, prefix, nlayers):
         """sample_and_group_all concatenates [xyz(3), features(512)] (pointnet2_utils.py:155); our
         buffers hold [features(512) | xyz(3) | 0 x 5] so that K = 520 is a multiple of 8."""
         for k in range(nlayers):
-            W, b = _fold(sd, f"{prefix}.mlp_convs.{k}", f"{prefix}.mlp_bns.{k}")
-            W = W[:, :, 0, 0]
+            W, b = F[f"{prefix}.{k}"]["W"], F[f"{prefix}.{k}"]["b"]
             if k == 0:
                 assert W.shape[1] == 515
                 W = np.concatenate([W[:, 3:], W[:, :3], np.zeros((W.shape[0], 5))], 1)
@@ -280,15 +442,12 @@ class PackedWeights:
         br.W2s = self._dev_bytes("clsm.W2s", i2)
         br.W3s = self._dev_bytes("clsm.W3s", i3)
 
-    def _fp_module(self, m, sd, prefix):
+    def _fp_module(self, m, F, prefix):
         """A three-layer feature-propagation MLP without skip input (fp1, TEHNet.py:129) in the form ev2h_fp_mlp takes: the first
         layer as a table over the coarse points (W1f, b1 -- it commutes with the interpolation), layers 2-3 as the tile images of
         the fused set-abstraction kernel."""
-        Ws, bs = [], []
-        for j in range(3):
-            W, b = _fold(sd, f"{prefix}.mlp_convs.{j}", f"{prefix}.mlp_bns.{j}")
-            Ws.append(W[:, :, 0])
-            bs.append(b)
+        Ws = [F[f"{prefix}.{j}"]["W"] for j in range(3)]
+        bs = [F[f"{prefix}.{j}"]["b"] for j in range(3)]
         C1, C2, C3 = (x.shape[0] for x in Ws)
         m.kf, m.npoint, m.nbranch = Ws[0].shape[1], 0, 1
         assert (C1, C2, C3) == (128, 128, 256) and m.kf % 32 == 0
@@ -310,15 +469,12 @@ class PackedWeights:
         m.w1f_norm = float(np.abs(Ws[0]).sum(1).max()) * (1 + 1e-6)
         m.b1_max = float(np.abs(bs[0]).max()) * (1 + 1e-6)
 
-    def _sa_module(self, m, sd, prefix, nfeat, kf, npoint, radii, nsamples):
+    def _sa_module(self, m, F, prefix, nfeat, kf, npoint, radii, nsamples):
         W1f, b1 = [], []
         m.kf, m.npoint, m.nbranch = kf, npoint, len(radii)
         for i, (r, K) in enumerate(zip(radii, nsamples)):
-            Ws, bs = [], []
-            for j in range(3):
-                W, b = _fold(sd, f"{prefix}.conv_blocks.{i}.{j}", f"{prefix}.bn_blocks.{i}.{j}")
-                Ws.append(W[:, :, 0, 0])
-                bs.append(b)
+            Ws = [F[f"{prefix}.{i}.{j}"]["W"] for j in range(3)]
+            bs = [F[f"{prefix}.{i}.{j}"]["b"] for j in range(3)]
             C1, C2, C3 = (x.shape[0] for x in Ws)
             assert Ws[0].shape[1] == nfeat + 3                 # [features..., dx, dy, dz] (pointnet2_utils.py:248)
             W1f.append(_pad(Ws[0][:, :nfeat], C1, kf))

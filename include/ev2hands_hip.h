@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 4
+#define EV2H_ABI_VERSION 5
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -137,8 +137,9 @@ typedef struct ev2h_gemm_desc {
 } ev2h_gemm_desc;
 int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream);
 
-/* [B*N][4] point-major logits -> class_logits [B,4,N] (TEHNet.py:188,197). */
-int ev2h_transpose_logits(const float* logits_pm, int B, int N, float* logits_cm, ev2h_stream_t stream);
+/* [B*N][4] point-major logits -> class_logits [B,4,N] (TEHNet.py:188,197).  cm_window_stride: floats between consecutive windows of
+ * logits_cm (0 = 4 * N, dense). */
+int ev2h_transpose_logits(const float* logits_pm, int B, int N, float* logits_cm, size_t cm_window_stride, ev2h_stream_t stream);
 
 /* ---- fused grouped set-abstraction MLP ----------------------------------------------------------- */
 /* out[b][s][c] = max_k relu(W3' relu(W2' relu(P1[b][gidx[b][s][k]] + W1x (xyz[idx] - ctr[b][s])) + b2') + b3')
@@ -215,8 +216,17 @@ typedef struct ev2h_fp_desc {
     int out_cols;                 /* 0 = C3                                                                           */
     int no_relu_out;              /* 1: no ReLU after the last layer                                                  */
     float* out_cm;                /* optional second copy of the output, channel-major [B][out_cols][N]               */
+    size_t out_cm_stride;         /* floats between consecutive windows of out_cm (0 = out_cols * N, dense)           */
 } ev2h_fp_desc;
 int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
+
+/* Geometry of the host-packed weight tile images (W2s / W3s of ev2h_sa_desc and ev2h_fp_desc, Ws of ev2h_gemm_desc) for a chain
+ * (C1, C2, C3) and `planes` operand planes (1 BF16, 2 F16X2, 3 BF16X3), straight from the kernels' compile-time configuration:
+ * out = { T2 (32-row layer-2 tiles), C2P (layer-3 contraction length in the permuted order), RS2, RS3 (bytes per LDS row of a
+ * W2 / W3 tile), TB2, TB3 (bytes per tile), GEMM RS (bytes per row of a dense W image tile), GEMM BK (k columns per tile) }.
+ * A host packer asserts its own layout against this (ev2hands_amd/pack.py does at load time), so the kernels and the packer
+ * cannot drift apart silently.  Needs no GPU. */
+int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[8]);
 
 /* ---- attention (model/TEHNet.py:13-27) ------------------------------------------------------------ */
 /* sim[b][h][c][d] = softmax_c( 256^-0.5 * sum_n logits[b][n][c] * query_h[b][n][d] ); query of hand h
@@ -237,9 +247,11 @@ size_t ev2h_attn_sim_folded_scratch(int B, int N);
 int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, int ldq, int B, int N, const float* w4t_left,
                          const float* w4t_right, const float* b4_left, const float* b4_right, float* scratch, float* sim,
                          ev2h_stream_t stream);
-/* hf8[h][b*N + n][0..3] = sum_d sim[b][h][c][d] * value[b*N+n][d]; columns 4..7 are written as 0. */
+/* hf8[h][b*N + n][0..3] = sum_d sim[b][h][c][d] * value[b*N+n][d]; columns 4..7 are written as 0.
+ * value_unscale: optional [256], value channel d is used as value[..][d] * value_unscale[d] (exact when the factors are powers of
+ * two: the host's channel equalisation stores fp1's output scaled per channel). */
 int ev2h_attn_context(const float* sim, const float* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax,
-                      int amax_hand_stride, ev2h_stream_t stream);
+                      int amax_hand_stride, const float* value_unscale, ev2h_stream_t stream);
                       /* hf_amax: optional range records, hand h at hf_amax[h * amax_hand_stride + b] */
 
 /* ---- MANO layer (manopth ManoLayer.forward behind model/utils.py:25-31) ----------------------------- */
@@ -255,9 +267,10 @@ typedef struct ev2h_mano_consts {
     int32_t ncomps;
 } ev2h_mano_consts;
 /* params [B][ldp] = global_orient(3) | hand_pose(ncomps) | betas(10) | transl(3)  (TEHNet.py:87-90).
- * verts [B][778][3], joints [B][21][3] in metres (mm scaling and /1000 of utils.py:28-29 included). */
-int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, float* joints,
-              ev2h_stream_t stream);
+ * verts [B][778][3], joints [B][21][3] in metres (mm scaling and /1000 of utils.py:28-29 included).
+ * verts_stride / joints_stride: floats between consecutive windows (0 = 2334 / 63, dense). */
+int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp, int B, float* verts, size_t verts_stride, float* joints,
+              size_t joints_stride, ev2h_stream_t stream);
 /* Parity access: rot [B][16][9] = the rotation matrices ev2h_mano derives from params (global orientation + 15 articulated joints;
  * axis-angle -> matrix by the formula of losses.py:14-51: quaternion route, theta + 1e-8 inside the norm).  Only hands_mean, comps
  * and ncomps of `c` are used. */
@@ -365,6 +378,9 @@ typedef struct ev2h_weights {
     ev2h_dense mano_sa2[2][2];
     ev2h_dense head0[2], head4[2];
     int precision;                               /* EV2H_PREC_* used by the MFMA kernels               */
+    const float* l0_unscale;                     /* [256] or NULL: ev2h_attn_context's value_unscale -- the per-channel powers of two
+                                                    the host's channel equalisation (pack.py: equalize_channels) multiplied fp1's
+                                                    output by; every other consumer of that tensor has them folded into its columns */
 } ev2h_weights;
 
 typedef struct ev2h_outputs {
@@ -372,6 +388,11 @@ typedef struct ev2h_outputs {
     float* params[2];             /* [B][22]   left, right                                             */
     float* vertices[2];           /* [B][778][3]                                                       */
     float* joints[2];             /* [B][21][3]                                                        */
+    /* Floats between consecutive WINDOWS of each output (0 = dense: 4N, 22, 2334, 63).  With all four set to one row width the
+     * forward writes a window's predictions side by side into one row of a caller-owned [B][row] matrix -- e.g. straight into
+     * this rank's slice of the all-gather buffer (ev2hands_amd/dist.py: [4N logits | left 22 + 2334 + 63 | right ...]), so that
+     * the multi-GPU path needs no packing copy. */
+    size_t logits_stride, params_stride, vertices_stride, joints_stride;
 } ev2h_outputs;
 
 size_t ev2h_workspace_bytes(int B, int N);

@@ -123,9 +123,16 @@ def penetration_loss(vertices, faces, pairs, sigma: float = 0.5):
     return float(sum(cone_term(tri[i], tri[j], sigma) + cone_term(tri[j], tri[i], sigma) for i, j in pairs))
 
 
-def collision_loss(verts_left, verts_right, faces_left, faces_right, max_collisions: int = 16, sigma: float = 0.5, weight: float = 1e2):
+def collision_loss(verts_left, verts_right, faces_left, faces_right, max_collisions: int = 16, sigma: float = 0.5, weight: float = 1e2,
+                   reference_batch_quirk: bool = False):
     """CollisionLoss.__call__ (losses.py:77-102) for a batch: verts_* [B,778,3] float32 METRES (the loss does not rescale).
-    Returns (loss value, per-window penalties)."""
+    Returns (loss value, per-window penalties).
+    Every window uses its OWN vertices.  Upstream does not for B > 1: losses.py:88-93 indexes `verts_tensor.view([-1, 3])` with
+    face indices that are not offset per batch item, so all B triangle sets are built from item 0's vertices and the upstream
+    value is 100 x window 0's penalty; reference_batch_quirk=True restates that."""
+    if reference_batch_quirk:
+        verts_left = [verts_left[0]] * len(verts_left)
+        verts_right = [verts_right[0]] * len(verts_right)
     per = []
     for vl, vr in zip(verts_left, verts_right):
         v, f = build_triangles(vl, vr, faces_left, faces_right, scale=1.0)

@@ -47,3 +47,17 @@ def test_world_size_mismatch_is_a_clear_error():
     env = dict(_clean_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--stub"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_a_rank_that_dies_ends_the_run_promptly_and_its_log_is_shown():
+    """the launcher used to block on rank 0, which sits in the rendezvous until its timeout when a peer is gone.  Now the
+    first non-zero exit terminates the other ranks and the failed rank's log tail is printed."""
+    import time
+    env = dict(_clean_env(), EV2H_BENCH_STUB_FAIL_RANK="1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--stub", "--batch", "2", "--points", "128"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert "simulated start-up failure" in p.stderr and "rank 1" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]              # no result line from a failed run
+    assert os.path.exists(os.path.join(ROOT, "gpurun_out", "bench_rank1.log"))

@@ -163,3 +163,43 @@ def test_gpu_collision_loss_matches_oracle():
     for b in (1, 4):
         vv, ff = CO.build_triangles(vl[b], vr[b], f, f, scale=1.0)
         assert int(c16[b]) == CO.collision_pairs(vv, ff, 16).shape[0]
+
+
+def test_reference_batch_quirk_is_restated():
+    """losses.py:88-93 indexes the flattened vertices of the whole batch with un-offset face indices: upstream's value for B > 1 is
+    100 x window 0's penalty.  Default here: every window its own vertices; the flag restates upstream."""
+    v, f = CO.icosphere(2)
+    vl = np.stack([(v * 0.040).astype(np.float32)] * 3)
+    vr = np.stack([(v * 0.040 + o).astype(np.float32) for o in ([0.05, 0.003, 0.001], [0.2, 0, 0], [0.03, 0.02, -0.01])])
+    own, per = CO.collision_loss(vl, vr, f, f)
+    quirk, perq = CO.collision_loss(vl, vr, f, f, reference_batch_quirk=True)
+    assert per[0] > 0 and per[1] == 0 and per[2] > 0
+    assert np.all(perq == per[0]) and quirk == pytest.approx(per[0] * 100) and own != pytest.approx(quirk)
+
+
+@pytest.mark.gpu
+def test_gpu_collision_loss_capacity_and_quirk():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ev2hands_amd.collision import CollisionLoss, device_faces
+    v, f = CO.icosphere(3)
+    B = 3
+    vl = np.stack([(v * 0.040).astype(np.float32)] * B)
+    vr = np.stack([(v * 0.040 + o).astype(np.float32) for o in ([0.01, 0.0, 0.0], [0.2, 0, 0], [0.03, 0.02, -0.01])])
+    outs = {"left": {"vertices": torch.from_numpy(vl).cuda(), "faces": f}, "right": {"vertices": torch.from_numpy(vr).cuda(), "faces": f}}
+    cl = CollisionLoss("cuda:0")
+    assert cl.capacity(f.shape[0]) == 2 * f.shape[0] * 16
+    per = cl.per_window(outs).cpu().numpy()
+    assert not cl.truncated()
+    want, want_per = CO.collision_loss(vl, vr, f, f)
+    assert np.allclose(per, want_per, rtol=1e-9, atol=1e-300)
+    # device face tensors prepared once give the same result and are passed through without a copy
+    df = device_faces(f, "cuda:0")
+    assert np.array_equal(cl.per_window(outs, faces=(df, df)).cpu().numpy(), per)
+    # a deliberately small pair list is reported as truncated
+    small = CollisionLoss("cuda:0", max_pairs=4)
+    small.per_window(outs)
+    assert small.truncated()
+    q = CollisionLoss("cuda:0", reference_batch_quirk=True)
+    wantq, _ = CO.collision_loss(vl, vr, f, f, reference_batch_quirk=True)
+    assert float(q(outs)) == pytest.approx(wantq, rel=1e-6)

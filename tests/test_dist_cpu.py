@@ -48,7 +48,43 @@ def _worker(rank, world, port, gB, N, q, pass_gb=True):
     dist.destroy_process_group()
 
 
+def _worker_inplace(rank, world, port, gB, N, q, steps=2):
+    """GatherBuffer: the 'forward' writes its windows straight into this rank's slice of the gather buffer (as ev2h_forward does
+    through ev2h_outputs' window strides), then ONE in-place all-gather; repeated, because the buffer is persistent."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = evdist.shard_range(gB, rank, world)
+    buf = evdist.GatherBuffer(N, gB, "cpu")
+    ok = buf.rows().shape == (hi - lo, evdist.packed_width(N)) and (hi == lo or buf.rows().data_ptr() == buf.full[rank * buf.big:].data_ptr())
+    for step in range(steps):
+        buf.rows().copy_(evdist.pack_outputs(_fake_outputs(lo + 100 * step, hi + 100 * step, N)))
+        full = buf.gather()
+        want = _fake_outputs(100 * step, gB + 100 * step, N)
+        ok = ok and torch.equal(full["class_logits"], want["class_logits"])
+        for side in ("left", "right"):
+            for k in want[side]:
+                ok = ok and torch.equal(full[side][k], want[side][k]) and full[side][k].shape == want[side][k].shape
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
 import pytest
+
+
+@pytest.mark.parametrize("gB", [6, 7, 1])
+def test_in_place_gather_buffer_world2(gB):
+    world, N = 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_inplace, args=(r, world, port, gB, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
 
 
 @pytest.mark.parametrize("gB,pass_gb", [(6, True), (7, True), (7, False), (1, True)])

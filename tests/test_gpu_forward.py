@@ -98,14 +98,19 @@ def check_against(out, net, ref, trace, B, N):
         if n:
             bad[tname] = n
     # intermediate features (diagnostics + tolerance)
+    # (the workspace holds the EQUALISED channels -- pack.py: equalize_channels multiplies channel c of a hidden tensor by the power
+    # of two e_c -- so the buffers are divided by those factors before they are compared with the reference's tensors)
     feats = {
-        "sa1_points": ("l1cat", (B, 512, 576), slice(0, 320)),
-        "l0_points": ("l0", (B, N, 256), slice(0, 256)),
+        "sa1_points": ("l1cat", (B, 512, 576), slice(0, 320), "sa1.out"),
+        "l0_points": ("l0", (B, N, 256), slice(0, 256), "l0"),
     }
-    for tname, (bname, shape, cols) in feats.items():
+    eq = net.net.packed(out["class_logits"].device).equalization
+    for tname, (bname, shape, cols, ename) in feats.items():
         if tname in trace:
-            got = net.net.debug_buffer(bname).view(shape)[:, :, cols].permute(0, 2, 1)
-            errs["buf." + tname] = rel(got, trace[tname])
+            got = net.net.debug_buffer(bname).view(shape)[:, :, cols]
+            if ename in eq:
+                got = got / torch.from_numpy(eq[ename]).to(got)
+            errs["buf." + tname] = rel(got.permute(0, 2, 1), trace[tname])
     same = bool((out["class_logits"].argmax(1).cpu() == torch.as_tensor(ref["class_logits"]).argmax(1)).all())
     print("errors:", {k: f"{v:.2e}" for k, v in errs.items()}, "selection mismatches:", bad, "argmax identical:", same)
     assert not bad, bad
@@ -453,6 +458,78 @@ def test_hipgraph_replay_is_bit_identical_to_eager(B, precision):
     assert g.out["left"]["faces"].shape == (B, 1538, 3)
 
 
+def test_captured_forward_owns_what_its_graph_points_at():
+    """A hipGraph bakes device addresses in.  The net's shared workspace is re-allocated by a later, larger eager forward, and the
+    packed weights are dropped when the precision or the parameters change: a captured forward therefore owns its workspace and
+    holds the packed weights it was captured with -- replays after such events stay bit-identical, or refuse to run."""
+    _need_gpu()
+    C, N, seed = 4, 1024, 19
+    net, sd, assets = make_net(C, seed, precision="f16x2")
+    x1 = synth.synth_cloud("E", 1, C, N, seed).cuda()
+    x8 = synth.synth_cloud("U", 8, C, N, seed + 1).cuda()
+    i1, i8 = synth.fps_inits(1, N, seed), synth.fps_inits(8, N, seed + 1)
+
+    def flat(o):
+        return torch.cat([o["class_logits"].flatten()] + [o[s][k].flatten() for s in ("left", "right")
+                                                           for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl")]).clone()
+    with torch.no_grad():
+        net.net.fps_init = i1
+        e1 = flat(net(x1))
+        g = net.capture(x1, fps_init=i1)
+        assert torch.equal(flat(g.replay()), e1)
+        net.net.fps_init = i8
+        net(x8)                                               # larger batch: the net's own workspace is freed and re-allocated
+        junk = torch.full((64 << 20,), 7.0, device="cuda")    # ... and whatever the allocator freed gets overwritten
+        assert torch.equal(flat(g.replay()), e1)
+        net.net.precision = "f32"                             # the eager path re-packs; the graph keeps the weights it captured
+        net.net.fps_init = i1
+        net(x1)
+        with pytest.raises(RuntimeError, match="capture again"):
+            g.replay()
+        net.net.precision = "f16x2"                           # back to the captured arithmetic (re-packed: same key)
+        net.net.fps_init = i1
+        net(x1)
+        assert torch.equal(flat(g.replay()), e1)
+        net.load_state_dict(synth.synth_state_dict(C, seed + 5), strict=True)
+        with pytest.raises(RuntimeError, match="capture again"):
+            g.replay()
+    torch.cuda.synchronize()
+    del junk
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f32"])
+def test_forward_into_caller_owned_rows(precision):
+    """ev2h_outputs' window strides: the forward writes every window's predictions as one row of a caller-owned matrix (the layout
+    of the multi-GPU gather buffer, ev2hands_amd/dist.py) -- bit-identical to the dense outputs, nothing written outside the
+    row's first packed_width columns, the returned tensors are views of the matrix."""
+    _need_gpu()
+    from ev2hands_amd import dist as evdist
+    C, N, B, seed = 5, 777, 3, 20
+    net, sd, assets = make_net(C, seed, precision=precision)
+    x = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    W = evdist.packed_width(N)
+    big = torch.full((B + 2, W + 5), -123.0, device="cuda")
+    rows = big[1:B + 1]                                       # a slice of a larger buffer, row stride W + 5
+    with torch.no_grad():
+        net.net.fps_init = inits
+        dense = net(x)
+        net.net.fps_init = inits
+        out = net.net(x, net.hands, rows=rows)
+    torch.cuda.synchronize()
+    assert out["class_logits"].data_ptr() == rows.data_ptr()
+    assert torch.equal(out["class_logits"], dense["class_logits"])
+    for side in ("left", "right"):
+        for k in ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl"):
+            assert torch.equal(out[side][k], dense[side][k]), (side, k)
+    back = evdist.unpack_outputs(rows[:, :W], N)
+    assert torch.equal(back["class_logits"], dense["class_logits"]) and torch.equal(back["right"]["j3d"], dense["right"]["j3d"])
+    assert torch.equal(evdist.pack_outputs(dense), rows[:, :W])
+    assert bool((big[0] == -123.0).all()) and bool((big[-1] == -123.0).all()) and bool((big[:, W:] == -123.0).all())
+    with pytest.raises(RuntimeError, match="rows must be"):
+        net.net(x, net.hands, rows=torch.empty(B, W - 1, device="cuda"))
+
+
 def test_two_stream_fork_is_bit_identical(tmp_path):
     """EV2H_TWO_STREAMS=1 (opt-in: right-hand regressor and the MANO ball queries on a second stream) must not change a bit.
     The switch is read once per process, so the forked run happens in a child process."""
@@ -487,3 +564,66 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         res[fork] = torch.load(out)
     assert torch.equal(res["0"], res["1"])
+
+
+# Every A/B switch the library reads from the environment (each `static const bool`, read once per process) selects an alternative
+# code path that is kept because DESIGN.md quotes its same-box timing.  A kept path must stay correct: each runs the whole forward in
+# a child process and is compared with the default path -- bit-identical where the arithmetic is the same, <= 1e-5 where the
+# switch re-associates sums (the un-fused / un-folded forms), selections and argmax identical in every case.
+AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_EXTRA_OVERLAP", "0", True), ("EV2H_SA_NO_SKIP", "1", True), ("EV2H_SA_STREAMED", "1", True),
+               ("EV2H_NO_TABLE_KERNEL", "1", True), ("EV2H_GEMM_NO_TAP3", "1", True), ("EV2H_NO_SKINNY_KERNEL", "1", False),
+               ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFOLDED", "1", False)]
+
+_AB_SCRIPT = """
+import os, sys, torch
+sys.path.insert(0, {root!r})
+from ev2hands_amd import synth
+from ev2hands_amd.model import TEHNetWrapper
+os.environ['ERPC'] = '1'
+assets = {{s: synth.synth_mano_assets(s, 3) for s in ('left', 'right')}}
+res = {{}}
+for prec in ('f16x2', 'bf16x3'):
+    net = TEHNetWrapper('cuda:0', mano_assets=assets, precision=prec)
+    net.load_state_dict(synth.synth_state_dict(5, 3), strict=True); net.eval()
+    xyz = synth.synth_cloud('E', 3, 5, 1100, 3).cuda()
+    net.net.fps_init = synth.fps_inits(3, 1100, 3)
+    with torch.no_grad():
+        o = net(xyz)
+    torch.cuda.synchronize()
+    res[prec] = {{'logits': o['class_logits'].cpu(), 'gidx': net.net.debug_buffer('gidxm1R', torch.int32).cpu(), 'nn': net.net.debug_buffer('nn1_idx', torch.int32).cpu(),
+                 **{{f'{{s}}.{{k}}': o[s][k].cpu() for s in ('left', 'right') for k in ('vertices', 'j3d', 'global_orient', 'hand_pose', 'betas', 'transl')}}}}
+torch.save(res, sys.argv[1])
+"""
+
+
+@pytest.fixture(scope="module")
+def ab_default(tmp_path_factory):
+    _need_gpu()
+    import subprocess
+    import sys
+    d = tmp_path_factory.mktemp("ab")
+    script = d / "run.py"
+    script.write_text(_AB_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = {k: v for k, v in os.environ.items() if k not in {n for n, _, _ in AB_SWITCHES}}
+    r = subprocess.run([sys.executable, str(script), str(d / "default.pt")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return script, env, torch.load(d / "default.pt")
+
+
+@pytest.mark.parametrize("name,value,bit_identical", AB_SWITCHES, ids=[n for n, _, _ in AB_SWITCHES])
+def test_ab_switch_paths_agree_with_the_default(ab_default, tmp_path, name, value, bit_identical):
+    import subprocess
+    import sys
+    script, env, want = ab_default
+    out = tmp_path / "alt.pt"
+    r = subprocess.run([sys.executable, str(script), str(out)], env=dict(env, **{name: value}), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = torch.load(out)
+    for prec in want:
+        for k, w in want[prec].items():
+            g = got[prec][k]
+            if bit_identical or k in ("gidx", "nn"):
+                assert torch.equal(g, w), (name, prec, k)
+            else:
+                assert rel(g, w) < 1e-5, (name, prec, k, rel(g, w))
+        assert torch.equal(got[prec]["logits"].argmax(1), want[prec]["logits"].argmax(1)), (name, prec)

@@ -35,7 +35,7 @@ def test_struct_layouts_and_abi_version(built):
     built.ev2h_struct_sizes(sizes)
     mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 4
+    assert built.ev2h_abi_version() == 5
 
 
 def test_workspace_size_grows_linearly(built):
@@ -116,7 +116,7 @@ def test_no_cpu_fallback():
 def test_packed_weight_layouts():
     from ev2hands_amd.pack import PackedWeights
     sd = synth.synth_state_dict(5, 3)
-    pw = PackedWeights(sd, "cpu", 5)
+    pw = PackedWeights(sd, "cpu", 5, equalize=False)      # (the equalisation multiplies rows / columns by powers of two: test_range_host.py)
     t = pw.tensors
     assert tuple(t["sa1.W1f"].shape) == (160, 8) and tuple(t["sa2.W1f"].shape) == (256, 320)
     assert tuple(t["sa2.1.W2"].shape) == (224, 128) and float(t["sa2.1.W2"][196:].abs().max()) == 0.0
@@ -170,3 +170,137 @@ def test_mano_pkl_reader_without_chumpy(tmp_path):
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights", "hands_components", "hands_mean"):
         assert np.allclose(got[k], a[k]), k
     assert got["parents"] == a["parents"] and np.array_equal(got["faces"], a["faces"])
+
+
+def test_tile_geometry_comes_from_the_kernels(built):
+    """One source of truth for the weight tile images: the library exports the kernels' compile-time geometry and
+    pack.py's image builders assert their own numbers against it on every pack; a drift raises at load time, not in a GPU parity
+    test.  No GPU needed."""
+    import ctypes as C
+    from ev2hands_amd import pack
+    out = (C.c_int * 8)()
+    assert built.ev2h_tile_geometry(128, 196, 256, 2, out) == 0
+    assert list(out) == [7, 208, 144, 848, 7 * 32 * 144, 32 * 848, 144, 32]
+    assert built.ev2h_tile_geometry(100, 100, 100, 2, out) != 0 and b"unsupported chain" in built.ev2h_last_error()
+    rng = np.random.default_rng(0)
+    for (c1, c2, c3) in ((32, 32, 64), (64, 96, 128), (128, 196, 256), (256, 256, 32)):
+        for ns in (1, 2, 3):
+            i2, i3, u2, u3 = pack.sa_bf16_images(rng.normal(size=(c2, c1)), rng.normal(size=(c3, c2)), ns)     # asserts inside
+            g = pack.kernel_geometry(c1, c2, c3, ns)
+            assert i2.size == (c1 // 32) * g["TB2"] and i3.size == (c3 // 32) * g["TB3"]
+    # a drifted packer is caught
+    real = pack.sa_bf16_geometry
+    pack.sa_bf16_geometry = lambda C2: (real(C2)[0], real(C2)[1] + 16)
+    try:
+        with pytest.raises(Exception, match="tile geometry"):
+            pack.sa_bf16_images(rng.normal(size=(196, 128)), rng.normal(size=(256, 196)), 2)
+    finally:
+        pack.sa_bf16_geometry = real
+
+
+# ---- real-asset hardening (VERDICT r2 #8): the day MANO_{LEFT,RIGHT}.pkl and best_model_state_dict.pth appear -----------------
+class _Py2Pickler(__import__("pickle")._Pickler):
+    """Writes what Python 2's cPickle wrote at protocol 2 -- the format of the licensed MANO files: `str` and raw array buffers as
+    (SHORT_)BINSTRING (bytes that Python 3 has to decode with encoding='latin1'), classes under their 2017 module paths
+    (numpy.core.multiarray, scipy.sparse.csc, chumpy.ch).  Pure-Python pickler with the str / bytes / global writers replaced."""
+    import pickle as _p
+    import struct as _s
+    dispatch = dict(_p._Pickler.dispatch)
+
+    def _binstring(self, b):
+        p, s = self._p, self._s
+        self.write((p.SHORT_BINSTRING + bytes([len(b)]) if len(b) < 256 else p.BINSTRING + s.pack("<i", len(b))) + b)
+
+    def save_str(self, obj):
+        self._binstring(obj.encode("latin1"))
+        self.memoize(obj)
+
+    def save_bytes(self, obj):
+        self._binstring(obj)
+        self.memoize(obj)
+
+    def save_global(self, obj, name=None):
+        name = name or getattr(obj, "__qualname__", obj.__name__)
+        module = getattr(obj, "__module__", None) or self._p.whichmodule(obj, name)
+        module = {"numpy._core.multiarray": "numpy.core.multiarray", "numpy._core.numeric": "numpy.core.numeric", "numpy": "numpy",
+                  "copyreg": "copy_reg"}.get(module, module)
+        self.write(self._p.GLOBAL + module.encode() + b"\n" + name.encode() + b"\n")
+        self.memoize(obj)
+
+    dispatch[str] = save_str
+    dispatch[bytes] = save_bytes
+
+
+def _fake_class(module, name):
+    """A picklable new-style class living under a foreign module path, state = its __dict__ (what chumpy.Ch and scipy's matrices do)."""
+    import sys
+    import types
+    mod = sys.modules.get(module) or types.ModuleType(module)
+    cls = type(name, (), {"__module__": module})
+    setattr(mod, name, cls)
+    return mod, cls
+
+
+def test_mano_pkl_reader_on_a_python2_style_file(tmp_path):
+    """The reader on a file with the REAL files' format features: Python-2 protocol-2 byte strings, chumpy objects pickled as
+    NEWOBJ + a state dict that carries chumpy's bookkeeping next to 'x', `scipy.sparse.csc.csc_matrix` under its 2017 module path
+    with the 2017 attribute set, uint32 faces, the 4294967295 root parent.  Neither chumpy nor the pickled scipy layout is needed."""
+    import io
+    import sys
+    from ev2hands_amd import mano
+    a = synth.synth_mano_assets("left", 2)
+    saved = {k: sys.modules.get(k) for k in ("chumpy", "chumpy.ch", "scipy.sparse.csc")}
+    made = {}
+    try:
+        for m in ("chumpy", "chumpy.ch"):
+            made[m], Ch = _fake_class(m, "Ch")
+            sys.modules[m] = made[m]
+        made["scipy.sparse.csc"], Csc = _fake_class("scipy.sparse.csc", "csc_matrix")
+        sys.modules["scipy.sparse.csc"] = made["scipy.sparse.csc"]
+
+        def ch(x):
+            o = Ch()
+            o.__dict__.update({"x": np.asarray(x), "_dirty_vars": set(), "_itr": None, "_depends_on_deps": {}, "_status": "new", "_cache": {"drs": {}}})
+            return o
+
+        jr = a["J_regressor"]
+        cols, rows = np.nonzero(jr.T)                                         # column-major order of the non-zeros
+        m = Csc()
+        m.__dict__.update({"_shape": jr.shape, "maxprint": 50, "data": jr[rows, cols].copy(), "indices": rows.astype(np.int32),
+                           "indptr": np.concatenate([[0], np.cumsum((jr != 0).sum(0))]).astype(np.int32), "_has_sorted_indices": True})
+        d = {"v_template": ch(a["v_template"]), "shapedirs": ch(a["shapedirs"]), "posedirs": ch(a["posedirs"]), "J_regressor": m,
+             "weights": ch(a["weights"]), "hands_components": a["hands_components"], "hands_mean": a["hands_mean"],
+             "hands_coeffs": np.zeros((3, 45)), "bs_style": "lbs", "bs_type": "lrotmin", "J": ch(np.zeros((16, 3))),
+             "f": a["faces"].astype(np.uint32), "kintree_table": np.array([[4294967295] + a["parents"][1:], list(range(16))], dtype=np.int64)}
+        buf = io.BytesIO()
+        _Py2Pickler(buf, protocol=2).dump(d)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    raw = buf.getvalue()
+    assert b"cchumpy.ch\nCh\n" in raw and b"cscipy.sparse.csc\ncsc_matrix\n" in raw and b"cnumpy.core.multiarray\n_reconstruct\n" in raw
+    assert b"U\nv_template" in raw                                            # SHORT_BINSTRING key: a Python-2 str
+    p = tmp_path / "MANO_LEFT.pkl"
+    p.write_bytes(raw)
+    assert "chumpy" not in sys.modules
+    got = mano.load_mano_pkl(str(p), "left")
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights", "hands_components", "hands_mean"):
+        assert np.array_equal(got[k], a[k]), k
+    assert got["parents"] == a["parents"] and np.array_equal(got["faces"], a["faces"]) and got["faces"].dtype == np.int64
+
+
+def test_checkpoint_with_the_other_input_width_is_refused_clearly():
+    """A C=4 checkpoint (ERPC=0) loaded into a model built with ERPC=1, and the other way round: a clear error naming ERPC, not a
+    size mismatch buried in strict loading; the validation tool refuses the same mismatch."""
+    from ev2hands_amd.model import TEHNetWrapper
+    assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
+    for env, ck_c in (("1", 4), ("0", 5)):
+        os.environ["ERPC"] = env
+        net = TEHNetWrapper("cpu", mano_assets=assets)
+        with pytest.raises(RuntimeError, match="ERPC"):
+            net.load_state_dict({"module." + k: v for k, v in synth.synth_state_dict(ck_c, 1).items()}, strict=True)
+        net.load_state_dict(synth.synth_state_dict(9 - ck_c, 1), strict=True)          # the matching width loads
+    os.environ["ERPC"] = "0"

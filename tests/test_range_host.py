@@ -99,3 +99,75 @@ def test_near_tie_head_produces_near_ties():
     assert float((m0 < 1e-3 * s0).float().mean()) == 0.0                    # the plain synthetic head never comes close to a tie
     assert float((m1 < 2e-5 * s1).float().mean()) > 0.01                    # the stress head does, for percent-level fractions
     assert len(torch.unique(tied["class_logits"].argmax(1))) >= 3           # and the classes really alternate
+
+
+# ------------------------------------------------------------------------------------------------ channel equalisation (pack.py)
+def _layer_spread(F):
+    """worst log2(max / min) over the hidden tensors of (row norm of the producer) and of (column norm of a consumer)"""
+    worst_r = worst_c = 0.0
+    for _, producers, consumers in pack.hidden_tensors():
+        r = np.concatenate([np.sqrt((F[l]["W"].reshape(F[l]["W"].shape[0], -1) ** 2).sum(1) + F[l]["b"] ** 2) *
+                            (np.abs(F[l]["ps"]) if k == "post" else 1.0) for l, k in producers])
+        n = r.shape[0]
+        worst_r = max(worst_r, float(np.log2(r.max() / r[r > 0].min())))
+        for l, off in consumers:
+            cols = F[l]["W"][:, off:off + n]
+            cn = np.sqrt((cols ** 2).sum(axis=tuple(i for i in range(cols.ndim) if i != 1)))
+            worst_c = max(worst_c, float(np.log2(cn.max() / cn[cn > 0].min())))
+    return worst_r, worst_c
+
+
+def test_hidden_tensor_table_matches_the_checkpoint_schema():
+    F = pack.fold_checkpoint(synth.synth_state_dict(5, 2))
+    seen_rows, seen_cols = set(), {}
+    for name, producers, consumers in pack.hidden_tensors():
+        n = sum(F[l]["W"].shape[0] for l, _ in producers)
+        for l, _ in producers:
+            assert l not in seen_rows, l                       # every layer's rows belong to exactly one tensor
+            seen_rows.add(l)
+        for l, off in consumers:
+            assert F[l]["W"].shape[1] >= off + n, (name, l)
+            for c in range(off, off + n):
+                assert (l, c) not in seen_cols, (name, l, c)
+            seen_cols.update({(l, c): name for c in range(off, off + n)})
+    # every input column of every layer is either a hidden channel or a raw input (coordinates / input features / hand features)
+    raw = {"sa1.0.0": 8, "sa1.1.0": 8, "sa1.2.0": 8, "sa2.0.0": 3, "sa2.1.0": 3, "sa3.0": 3}
+    for side in ("left", "right"):
+        p = f"{side}_mano_regressor"
+        raw.update({p + ".sa1.0.0": 7, p + ".sa1.1.0": 7, p + ".sa2.0": 3})
+    for l, L in F.items():
+        covered = sum(1 for c in range(L["W"].shape[1]) if (l, c) in seen_cols)
+        assert covered + raw.get(l, 0) == L["W"].shape[1], (l, covered, L["W"].shape)
+
+
+@pytest.mark.parametrize("log2_spread", [8, 16])
+def test_equalisation_undoes_per_channel_rescaling(log2_spread):
+    """A checkpoint whose hidden channels were rescaled by 2^+-s (synth.rescale_channels: same network, other representative)
+    packs to an equally well-conditioned representation: the accumulated factors absorb the rescaling up to the power-of-
+    two rounding, and the row / column spreads the 16-bit planes see are those of the original checkpoint, not 2^(2s)."""
+    sd = synth.synth_state_dict(4, 9)
+    F0 = pack.fold_checkpoint(sd)
+    F1 = pack.fold_checkpoint(synth.rescale_channels(sd, log2_spread, 9))
+    r_raw, c_raw = _layer_spread(F1)
+    assert r_raw > 1.5 * log2_spread and c_raw > 1.5 * log2_spread
+    e0, e1 = pack.equalize_channels(F0), pack.equalize_channels(F1)
+    for k, e in e1.items():
+        assert np.all(np.log2(e) == np.round(np.log2(e))), k                          # exact powers of two
+    r_eq, c_eq = _layer_spread(F1)
+    r_ref, c_ref = _layer_spread(F0)
+    assert r_eq <= r_ref + 2.5 and c_eq <= c_ref + 2.5, (r_eq, r_ref, c_eq, c_ref)
+
+
+def test_equalised_pack_is_a_power_of_two_rescaling():
+    """Equalised vs plain packing of one checkpoint: every packed fp32 weight differs by an exact power of two (or is equal), so
+    every fp32 product and partial sum of the exact mode changes by an exact power of two as well."""
+    sd = synth.synth_state_dict(5, 3)
+    a = pack.PackedWeights(sd, "cpu", 5, "f32", equalize=False)
+    b = pack.PackedWeights(sd, "cpu", 5, "f32", equalize=True)
+    assert b.equalization and not a.equalization
+    for k, ta in a.tensors.items():
+        tb = b.tensors[k]
+        nz = ta != 0
+        assert torch.equal(nz, tb != 0), k
+        q = torch.log2((tb[nz] / ta[nz]).double())
+        assert torch.equal(q, q.round()), k

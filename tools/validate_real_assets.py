@@ -181,6 +181,8 @@ def check_fixture(fixture: str, mano_dir: str, ckpt: str, precisions=("f32", "f1
     C = int(g["channels"])
     os.environ["ERPC"] = "1" if C == 5 else "0"
     sd = load_checkpoint(ckpt)
+    if channels_of(sd) != C:
+        raise RuntimeError(f"the checkpoint has {channels_of(sd)} input channels, the fixture was made with {C} (ERPC mismatch)")
     report = {}
     for prec in precisions:
         net = TEHNetWrapper(device, mano_path=mano_dir, precision=prec)
