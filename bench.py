@@ -66,6 +66,8 @@ def parse(argv=None):
     ap.add_argument("--no-legs", "--no-f32-leg", dest="no_legs", action="store_true", help="skip the timing legs of the other arithmetic modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live HBM-traffic measurement (two rocprofv3 PMC passes of a 3-step child run of this script)")
     ap.add_argument("--collision", action="store_true",
                     help="BASELINE config 5: add the two-hand self-collision term to every step (pair search with the evaluation's "
                          "max_collisions = 8, then the intersection loss's pair search with 16 and its distance-field penalty)")
@@ -168,22 +170,75 @@ class HipEvents:
         return out
 
 
-def pmc_traffic(precision="f32"):
-    """(HBM bytes per launch of the profiled kernel, source file) from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_hbm_traffic_*.json: (2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction); (None, None) if absent."""
+PROFILED_KERNEL_KEY = "128, 196, 256"          # template arguments that name the profiled kernel in a trace
+HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# SURVEY.md 8d per window at N=2048, C=4: boundary I/O, the fused stage-boundary estimate, the unfused reference-style estimate
+ALG_IO_BYTES_PER_WINDOW = 84888
+SURVEY_FUSED_BYTES_PER_WINDOW = 16.5e6
+SURVEY_UNFUSED_BYTES_PER_WINDOW = 1.99e9
+
+
+def committed_pmc_traffic(precision="f32"):
+    """Fallback: ({"kernel": bytes per launch of the profiled kernel, "step": bytes per forward step or None}, source file) from
+    the newest committed rocprofv3 PMC summary (profiles/r*_pmc_hbm_traffic_<mode>*.json, tools/pmc_traffic.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_*.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}.json")))
     if not files:
         return None, None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
-        k = ks[[n for n in ks if "128, 196, 256" in n][0]]
-        return k["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])
+        j = json.load(open(files[-1]))
+        ks = j["kernels"]
+        k = ks[[n for n in ks if PROFILED_KERNEL_KEY in n][0]]
+        return {"kernel": k["hbm_bytes_per_launch_corrected"], "step": j.get("step_hbm_bytes_corrected")}, os.path.basename(files[-1])
     except Exception:
         return None, None
 
 
-def roofline_entry(precision, B, kernel_ms_list):
+def live_pmc_traffic(a, timeout_s=300):
+    """HBM traffic measured IN THIS RUN: two rocprofv3 passes (one PMC counter each, FETCH_SIZE then WRITE_SIZE, with --kernel-trace
+    only -- the collection MI355X_MICROARCH.md prescribes) of a 3-forward child run of this very script, read from rocprofv3's
+    sqlite output.  gfx950 correction: both counters are in KiB and FETCH_SIZE counts 64 B per 128 B request, so
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Returns {"kernel": bytes per launch of the profiled kernel, "step": bytes per
+    forward step (sum over EVERY dispatch / 3)} or raises."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    nsteps = 3
+    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic",
+             "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud]
+    tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
+    env["TMPDIR"] = "/tmp"
+    sums = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            # the program itself follows `--` (no env / shell / launcher hop: the profiler's preloaded library has initialised the GPU)
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", "python3"] + child, cwd="/tmp", env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                raise RuntimeError(f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stdout or '')[-400:]}")
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? group by kernel_name, dispatch_id",
+                (ctr,)).fetchall()
+            if not rows:
+                raise RuntimeError(f"no {ctr} samples in {dbs[0]}")
+            prof = [v for k, _, v in rows if PROFILED_KERNEL_KEY in k and "sa_mlp_max" in k]
+            sums[ctr] = (sum(v for _, _, v in rows), sum(prof) / max(len(prof), 1), len(prof))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"kernel": int((2 * sums["FETCH_SIZE"][1] + sums["WRITE_SIZE"][1]) * 1024),
+            "step": int((2 * sums["FETCH_SIZE"][0] + sums["WRITE_SIZE"][0]) * 1024 / nsteps),
+            "kernel_launches_sampled": sums["FETCH_SIZE"][2]}
+
+
+def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None):
     """Dominant-kernel roofline: algorithmic fp32 FLOPs of the layer (2 x MACs) over the HIP-event duration, against the dense peak of
     the matrix pipe the mode uses; the plane products the split modes execute are reported separately."""
     kavg = sum(kernel_ms_list) / max(len(kernel_ms_list), 1)
@@ -191,15 +246,33 @@ def roofline_entry(precision, B, kernel_ms_list):
     peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
     alg_flops = 2.0 * PROFILED_MAC_PER_WINDOW * B
     alg = alg_flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(precision)
+    if traffic is None:
+        t, src = committed_pmc_traffic(precision)
+        if t is not None:
+            traffic, traffic_src = t["kernel"], "committed profile profiles/%s (not measured in this run)" % src
     return {"bound": "mfma", "kernel": f"sa_mlp_max<128,196,256> ({PROFILED_TAG}, K=128, {B} windows/launch, {precision})",
             "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
             "accounting": "algorithmic fp32 multiply-adds x 2 / HIP-event kernel time / dense peak of the MFMA type used",
             "executed": round(alg * nprod, 2), "executed_frac": round(alg * nprod / peak, 4), "products_per_mac": nprod,
             "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/%s)" % traffic_src if traffic_src else None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes", "traffic_source": traffic_src,
             "kernel_ms": round(kavg, 4), "kernel_samples": len(kernel_ms_list),
             "flop_per_launch": alg_flops}
+
+
+def hbm_entry(B, N, ms_per_step, step_bytes, source):
+    """Whole-step HBM view (north_star: "achieved fraction of the HBM roofline"): bytes every kernel of one forward moves (PMC) over
+    the step time, against 8 TB/s, next to SURVEY 8d's brackets.  The path is matrix-pipe bound (233 kFLOP per algorithmic byte), so
+    this fraction says how much HBM time the step needs, not how fast it could be."""
+    scale = N / 2048.0
+    gbs = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else None
+    return {"bound": "hbm", "bytes_per_step": step_bytes, "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None, "source": source,
+            "hbm_time_share_of_step": round(step_bytes / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4) if step_bytes else None,
+            "algorithmic_io_bytes_per_step": int(ALG_IO_BYTES_PER_WINDOW * B * scale),
+            "survey_fused_boundary_bytes_per_step": int(SURVEY_FUSED_BYTES_PER_WINDOW * B * scale),
+            "survey_unfused_reference_bytes_per_step": int(SURVEY_UNFUSED_BYTES_PER_WINDOW * B * scale),
+            "note": "bytes_per_step = sum over every kernel dispatch of one forward of (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
 
 
 def cpu_baseline(sd, assets, C_, N, cloud, seconds):
@@ -417,11 +490,25 @@ def run_rank(a) -> int:
             res["gathered_rows"] = int(last["class_logits"].shape[0]) if last is not None else None
             res["gathered_rank_ids"] = sorted({int(v) for v in last["class_logits"][:, 0, 0].tolist()}) if last is not None else None
         else:
-            res["roofline"] = roofline_entry(a.precision, B, main_kernel_ms)
+            live, live_src = None, None
+            if world == 1 and not a.no_traffic:
+                try:
+                    live = live_pmc_traffic(a)
+                    live_src = "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace passes of a 3-forward child run"
+                except Exception as e:  # noqa: BLE001 -- never lose the throughput line to the profiler
+                    live_src = f"live PMC passes failed ({type(e).__name__}: {str(e)[:200]})"
+            if live is None:
+                t, src = committed_pmc_traffic(a.precision)
+                if t is not None:
+                    live, live_src = t, (live_src + "; " if live_src else "") + f"committed profile profiles/{src} (not measured in this run)"
+            res["roofline"] = roofline_entry(a.precision, B, main_kernel_ms, live["kernel"] if live else None, live_src)
+            res["hbm"] = hbm_entry(B, N, dt / a.steps * 1e3, live.get("step") if live else None, live_src)
             f32_leg = legs.pop("f32", None)
             if f32_leg:
                 res["f32_mfma_leg"] = f32_leg
                 res["roofline_f32"] = roofline_entry("f32", B, leg_kernel_ms["f32"])
+            if "bf16" in legs:                  # BASELINE.json config 3 names this arithmetic: its own roofline entry
+                res["roofline_bf16"] = roofline_entry("bf16", B, leg_kernel_ms["bf16"])
             if legs:
                 res["other_modes"] = legs
             if latency:

@@ -105,18 +105,30 @@ class TEHNet(nn.Module):
         self._packed = None
         self._packed_key = None
         self._key_tensors = None
+        self._key_gen = 0
         self._faces_cache = {}
         self._ws = None
         self.fps_init = None          # optional override: list of four [B] int64 tensors for the next forward
 
     # -- weight packing (re-done whenever parameters/buffers change or move) ---------------------
-    def _pack_key(self):
+    def _key_list(self):
         # (walking the module tree costs ~2 ms per call -- more than a B = 1 forward; the tensor list is cached and dropped
         # whenever nn.Module machinery may have replaced tensor objects: _apply (.to / .cuda / .float) and load_state_dict)
         ts = self._key_tensors
         if ts is None:
             ts = self._key_tensors = list(self.parameters()) + list(self.buffers())
-        return (str(ts[0].device), tuple((t.data_ptr(), t._version) for t in ts))
+            self._key_gen += 1
+        return ts
+
+    def _pack_key(self):
+        """changes whenever a parameter / buffer is modified in place, replaced or moved"""
+        ts = self._key_list()
+        return (str(ts[0].device), self._key_gen, [t.data_ptr() for t in ts], [t._version for t in ts])
+
+    def _version_key(self):
+        """the cheap part of _pack_key (in-place modifications, module-level replacement): what a captured graph re-checks per replay"""
+        ts = self._key_list()
+        return (self._key_gen, [t._version for t in ts])
 
     def _apply(self, fn, *args, **kwargs):
         self._key_tensors = None
@@ -295,7 +307,7 @@ class CapturedForward:
         # the precision change (a replay would then read and write freed memory).
         self._ws = torch.empty(_lib.lib().ev2h_workspace_bytes(B, N), dtype=torch.uint8, device=device)
         self._pw = net.packed(device)
-        self._key = (net.precision, net.equalize, net._pack_key())
+        self._key = (net.precision, net.equalize, net._version_key())
         for s in ("left", "right"):
             mano_hands[s].consts()
         self._mano_keep = {s: (mano_hands[s]._keep, mano_hands[s].shapedirs._version) for s in ("left", "right")}    # MANO constant tensors
@@ -314,7 +326,7 @@ class CapturedForward:
     def replay(self, xyz=None, fps_init=None) -> dict:
         """Run the captured forward (optionally on new inputs of the captured shape).  The returned tensors are the graph's static
         outputs: they are overwritten by the next replay."""
-        if (self.net.precision, self.net.equalize, self.net._pack_key()) != self._key:
+        if (self.net.precision, self.net.equalize, self.net._version_key()) != self._key:
             raise RuntimeError("the network's parameters, device or precision changed since this forward was captured: the graph "
                                "holds the old packed weights -- capture again")
         if any(self.hands[s].shapedirs._version != self._mano_keep[s][1] for s in ("left", "right")):
