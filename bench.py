@@ -325,6 +325,7 @@ def run_rank(a) -> int:
     import torch
     from ev2hands_amd import dist as evdist, synth
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # before the first HIP call of this process (see ev2h_init below)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -341,6 +342,14 @@ def run_rank(a) -> int:
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    if not a.stub:
+        # HIP multiplexes a process's streams onto a few hardware queues (4 by default) and streams that share one run in order.
+        # torch.distributed / RCCL create dozens of streams; when the forward's side stream was created after them it landed on
+        # the main stream's queue and the two-stream overlaps silently vanished: that, not the gather, was the "4-5 % multi-GPU
+        # overhead at world size 1" of round 2 (profiles/r3_dist_overhead.txt).  So: the library's side stream is created FIRST
+        # (ev2h_init), and the process asks for 8 hardware queues (read by the HIP runtime when it initialises).
+        from ev2hands_amd import _lib as _early
+        _early.check(_early.lib().ev2h_init(), "ev2h_init")
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -34,7 +34,15 @@ extern "C" void ev2h_struct_sizes(size_t out[7]) {
     out[6] = sizeof(ev2h_fp_desc);
 }
 
-extern "C" int ev2h_init(void) { return ev2h_gemm_init(); }     // per-device, thread-safe, idempotent (common.hpp: PerDevice)
+static struct SideCtx* side_ctx();
+// per-device, thread-safe, idempotent (common.hpp: PerDevice).  Also creates the calling thread's side stream on the current device
+// NOW: HIP multiplexes streams onto a few hardware queues, and two streams that share one run in order -- a host that is going to
+// create many more streams (torch's stream pool, RCCL's) should call this first, so that the forward's side stream gets a hardware
+// queue of its own instead of landing on the caller's (measured: the two-stream overlaps, ~5 % of the step, silently vanish).
+extern "C" int ev2h_init(void) {
+    (void)side_ctx();
+    return ev2h_gemm_init();
+}
 
 // ---------------------------------------------------------------------------------------- profiling hook
 // bench.py brackets ONE named launch site of ev2h_forward with caller-owned HIP events (recorded on the
@@ -76,11 +84,12 @@ static inline void prof_end(const char* tag, ev2h_stream_t st) {
 // MFMA-heavy kernels of the other and fill their tails: +1.5-2 % windows/s at B=256, outputs bit-identical
 // (tests/test_gpu_forward.py::test_two_stream_fork_is_bit_identical).  EV2H_TWO_STREAMS=0 keeps everything on the caller's
 // stream.  Kernels of the two hands then overlap in time, so bench.py brackets a launch site before the fork (sa2.1).
-// One side stream (+ 4 events) per host thread AND per device: a second wrapper on another GPU in the same thread gets
+// One side stream (+ its events) per host thread AND per device: a second wrapper on another GPU in the same thread gets
 // its own stream on that device.
 struct SideCtx {
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr int NEV = 10;
+    hipEvent_t ev[NEV] = {};
     int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
 };
 constexpr int EV2H_MAX_DEVICES = 16;
@@ -95,7 +104,7 @@ static SideCtx* side_ctx() {     // the current device's side stream, or nullptr
         c.state = -1;
         if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess) {
             bool ok = true;
-            for (int i = 0; i < 8; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < SideCtx::NEV; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;
             if (ok) c.state = 1;
         }
     }
@@ -387,6 +396,8 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     static const bool extra = !(getenv("EV2H_EXTRA_OVERLAP") && atoi(getenv("EV2H_EXTRA_OVERLAP")) == 0);   // A/B: table + classifier on the side stream
     ev2h_stream_t sd = fork ? (ev2h_stream_t)side->stream : st;
     ev2h_stream_t sx = (fork && extra) ? sd : st;
+    static const bool coord = !(getenv("EV2H_COORD_OVERLAP") && atoi(getenv("EV2H_COORD_OVERLAP")) == 0);   // A/B: coordinate-only selections on the side stream
+    ev2h_stream_t sc = coord ? sx : st;
     if (fork) {
         EV2H_CHECK_HIP(hipEventRecord(side->ev[4], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[4], 0));
@@ -401,10 +412,28 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         float* ctr[3] = {ws.f("ctr1"), ws.f("ctrmL"), ws.f("ctrmR")};
         RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
     }
-    // fork 1: both hands' ball queries only need the raw cloud and their centroids
+    // fork 1: everything that needs only COORDINATES runs on the side stream, under the MFMA-bound set-abstraction kernels of
+    // enc.sa1 on the caller's stream (it used to sit between them on the critical path): the sampling and the ball query of
+    // enc.sa2 (its input points are enc.sa1's centroids), the 3-NN selection of fp1 (raw cloud against those centroids), then
+    // both hands' ball queries.  Same kernels, same inputs: bit-identical.
     if (fork) {
         EV2H_CHECK_HIP(hipEventRecord(side->ev[0], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[0], 0));
+    }
+    int32_t* gi2[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
+    {
+        const ev2h_sa_module& m = w->sa2;
+        RUN(ev2h_fps(ws.f("ctr1"), B, 512, 128, fps_init + (size_t)B, ws.i("fps2"), ws.f("ctr2"), sc));
+        double rad[2]; int ns[2];
+        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
+        RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi2, ws.i("cnt2"), sc));
+        if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[8], side->stream));
+    }
+    static const bool unfused_fp1 = getenv("EV2H_FP1_UNFUSED") != nullptr;      // A/B switch
+    const bool fp1_fused = prec != EV2H_PREC_F32 && w->fp1m.W1fs && !unfused_fp1;
+    if (fp1_fused) {
+        RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, nullptr, 0, 0, nullptr, 0, ws.i("nn1_idx"), ws.f("nn1_w"), nullptr, sc));
+        if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[9], side->stream));
     }
     for (int h = 0; h < 2; ++h) {
         const ev2h_sa_module& m = w->mano_sa1[h];
@@ -426,15 +455,11 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(sa_branches(prec, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
                         ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A)));
     }
-    // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points
+    // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {
         const ev2h_sa_module& m = w->sa2;
-        RUN(ev2h_fps(ws.f("ctr1"), B, 512, 128, fps_init + (size_t)B, ws.i("fps2"), ws.f("ctr2"), st));
-        double rad[2]; int ns[2];
-        int32_t* gi[2] = {ws.i("gidx2_0"), ws.i("gidx2_1")};
-        for (int i = 0; i < 2; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
-        RUN(ev2h_ball_query(ws.f("ctr1"), ws.f("ctr2"), B, 512, 128, 2, rad, ns, gi, ws.i("cnt2"), st));
-        RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
+        if (fork && extra && coord) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[8], 0));
+        RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi2, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
                       ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2)));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
                                                                                    ws.f("l2buf"), 520, 512);
@@ -455,13 +480,12 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st, rg(R_L1A, 512, R_FP2H, 512, R_L1B)));
     RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st, rg(R_FP2H, 512, R_L1NEW, 512)));
     // ---- fp1 (TEHNet.py:186): 3-NN 512 -> N, no skip
-    static const bool unfused_fp1 = getenv("EV2H_FP1_UNFUSED") != nullptr;      // A/B switch
-    if (prec != EV2H_PREC_F32 && w->fp1m.W1fs && !unfused_fp1) {
+    if (fp1_fused) {
         // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
         // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
         // the two hidden layers (3 x 268 MB written and read back at B = 256) never reach memory
         const ev2h_sa_module& m = w->fp1m;
-        RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, nullptr, 0, 0, nullptr, 0, ws.i("nn1_idx"), ws.f("nn1_w"), nullptr, st));
+        if (fork && extra && coord) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[9], 0));      // 3-NN selection: fork 1 above
         RUN(sa_table(prec, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
         ev2h_fp_desc d{};
         d.T = ws.f("fp1T"); d.ldt = 128; d.nn_idx = ws.i("nn1_idx"); d.nn_w = ws.f("nn1_w");

@@ -363,6 +363,11 @@ class TEHNetWrapper:
             self.net.precision = precision
         self.net.eval()
         self.training = False
+        if torch.device(device).type == "cuda":
+            # create the forward's side stream now: streams created later (torch's pool, RCCL) must not push it onto the caller's
+            # hardware queue (ev2h_init)
+            with torch.cuda.device(device):
+                _lib.check(_lib.lib().ev2h_init(), "ev2h_init")
         self.hands = create_mano_layers(mano_path, device, synth.MANO_CMPS, assets=mano_assets)
         self.rot = _rotation_x_180().to(device).float()
 

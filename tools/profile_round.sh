@@ -13,7 +13,7 @@ O=gpurun_out
 BENCH="bench.py --steps 7 --warmup 3 --no-legs --no-latency --no-cpu-baseline --no-traffic"
 SMALL="bench.py --steps 2 --warmup 1 --no-legs --no-latency --no-cpu-baseline --no-traffic"
 for prec in f16x2 f32 bf16x3 bf16; do
-  rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_$prec -o bench -- python3 $BENCH --precision $prec > $O/${TAG}_kt_$prec.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_$prec -o bench -- python3 $BENCH --precision $prec > $O/${TAG}_ktlog_$prec.txt 2>&1
   python tools/rocpd_summary.py $(ls $O/${TAG}_kt_$prec/*/*.db $O/${TAG}_kt_$prec/*.db 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats_$prec.txt 2>&1
 done
 export EV2H_TWO_STREAMS=0
@@ -42,4 +42,6 @@ done
   KBENCH_ZERO=1 KBENCH_PREC=f16x2 python tools/kbench.py sab
 } > $O/${TAG}_mfma_ceiling.txt 2>&1
 rm -f $O/mfma_power
+# the raw rocprofv3 databases are tens of MiB each and gpurun copies back at most 64 MiB: keep the summaries only
+rm -rf $O/${TAG}_kt_* $O/${TAG}_pmc_fetch_* $O/${TAG}_pmc_write_* $O/${TAG}_pmc_sq_a_* $O/${TAG}_pmc_sq_b_*
 ls -la $O | grep ${TAG}_ | head -60

@@ -14,7 +14,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Clk { unsigned long long core, ref; };
 
-template <int WAVES>
+// PATTERN 0: four consecutive MFMAs share the B operand and take different A operands (what the loop nests of the library do: one
+//            activation fragment against several weight fragments); 1: both operands change at every MFMA; 2: both operands fixed.
+template <int WAVES, int PATTERN>
 __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, float* __restrict__ out, Clk* __restrict__ clk, int iters) {
     f32x16 acc[4];
 #pragma unroll
@@ -33,7 +35,9 @@ __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, 
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[u], acc[a], 0, 0, 0);
+                acc[a] = PATTERN == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[u], acc[a], 0, 0, 0)
+                       : PATTERN == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[(u + 3 * a) & 3], acc[a], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc[a], 0, 0, 0);
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -45,20 +49,20 @@ __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, 
     if (threadIdx.x == 0) { clk[blockIdx.x].core = c1 - c0; clk[blockIdx.x].ref = r1 - r0; }
 }
 
-template <int WAVES>
+template <int WAVES, int PATTERN = 0>
 static void run(const char* label, const f16x8* d_ops, int ncu) {
     float* d_out; Clk* d_clk;
     hipMalloc(&d_out, (size_t)ncu * 256 * WAVES * sizeof(float));
     hipMalloc(&d_clk, ncu * sizeof(Clk));
     const int iters = 60000;                                      // ~50-100 ms: long enough for the power management to settle
-    k<WAVES><<<ncu, 256 * WAVES>>>(d_ops, d_out, d_clk, 2000);
+    k<WAVES, PATTERN><<<ncu, 256 * WAVES>>>(d_ops, d_out, d_clk, 2000);
     hipDeviceSynchronize();
     hipEvent_t s, e;
     hipEventCreate(&s); hipEventCreate(&e);
     float best = 1e30f, worst = 0.f; double clk_mhz = 0;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(s);
-        k<WAVES><<<ncu, 256 * WAVES>>>(d_ops, d_out, d_clk, iters);
+        k<WAVES, PATTERN><<<ncu, 256 * WAVES>>>(d_ops, d_out, d_clk, iters);
         hipEventRecord(e);
         hipEventSynchronize(e);
         float ms; hipEventElapsedTime(&ms, s, e);
@@ -70,7 +74,7 @@ static void run(const char* label, const f16x8* d_ops, int ncu) {
     }
     const double mfma = (double)iters * 16 * 4 * WAVES * ncu;     // per SIMD x 4 SIMDs x CUs
     const double flop = mfma * 32768.0;
-    printf("%-7s waves/SIMD=%d : %8.3f ms (worst of 5: %8.3f)  %7.1f TFLOP/s  = %.3f of 2500 dense peak   shader clock %.0f MHz  "
+    printf("%-8s waves/SIMD=%d : %8.3f ms (worst of 5: %8.3f)  %7.1f TFLOP/s  = %.3f of 2500 dense peak   shader clock %.0f MHz  "
            "(%.2f cycles per MFMA per SIMD)\n", label, WAVES, best, worst, flop / (best * 1e-3) / 1e12, flop / (best * 1e-3) / 2.5e15, clk_mhz,
            best * 1e-3 * clk_mhz * 1e6 / ((double)iters * 16 * WAVES));
     hipFree(d_out); hipFree(d_clk);
@@ -91,6 +95,10 @@ int main() {
         hipMemcpy(d_ops, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice);
         run<1>(pass == 0 ? "zeros" : "random", d_ops, ncu);
         run<2>(pass == 0 ? "zeros" : "random", d_ops, ncu);
+        if (pass == 1) {
+            run<2, 1>("rnd A+B", d_ops, ncu);          // both operands change at every MFMA
+            run<2, 2>("rnd fix", d_ops, ncu);          // the same random operands at every MFMA
+        }
     }
     return 0;
 }
