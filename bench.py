@@ -35,6 +35,10 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_16BIT_MFMA_TFLOPS = 2500.0    # same table, dense bf16 / fp16 matrix peak
+# What the matrix pipe SUSTAINS on random operands: a pure v_mfma_f32_32x32x16_f16 loop on every CU (no memory, no VALU) runs at
+# 0.98 of the peak on all-zero operands and at 0.68 of it on random ones -- the clock drops from 2.39 to ~1.68 GHz under the power
+# limit (tools/ubench/mfma_power.hip, profiles/r3_mfma_ceiling.txt).  A kernel that also feeds the pipe cannot beat that.
+SUSTAINED_16BIT_MFMA_TFLOPS = 1700.0
 # plane products executed per algorithmic multiply-add in each arithmetic mode
 PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1}
 DTYPE = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
@@ -255,6 +259,9 @@ def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None)
             "accounting": "algorithmic fp32 multiply-adds x 2 / HIP-event kernel time / dense peak of the MFMA type used",
             "executed": round(alg * nprod, 2), "executed_frac": round(alg * nprod / peak, 4), "products_per_mac": nprod,
             "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
+            **({"sustained_peak": SUSTAINED_16BIT_MFMA_TFLOPS, "executed_frac_of_sustained": round(alg * nprod / SUSTAINED_16BIT_MFMA_TFLOPS, 4),
+                "sustained_source": "pure MFMA loop on random operands at the power-limited clock, profiles/r3_mfma_ceiling.txt"}
+               if precision != "f32" else {}),
             "traffic": traffic, "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes", "traffic_source": traffic_src,
             "kernel_ms": round(kavg, 4), "kernel_samples": len(kernel_ms_list),
             "flop_per_launch": alg_flops}

@@ -11,9 +11,11 @@
 #include <vector>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Clk { unsigned long long core, ref; };
 
+// PATTERN 3: v_mfma_f32_32x32x16_bf16 on the same bit patterns; 4: v_mfma_f32_32x32x2_f32 (the exact-fp32 mode's instruction).
 // PATTERN 0: four consecutive MFMAs share the B operand and take different A operands (what the loop nests of the library do: one
 //            activation fragment against several weight fragments); 1: both operands change at every MFMA; 2: both operands fixed.
 template <int WAVES, int PATTERN>
@@ -35,9 +37,14 @@ __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, 
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int a = 0; a < 4; ++a)
-                acc[a] = PATTERN == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[u], acc[a], 0, 0, 0)
-                       : PATTERN == 1 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[(u + 3 * a) & 3], acc[a], 0, 0, 0)
-                                      : __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc[a], 0, 0, 0);
+            {
+                if constexpr (PATTERN == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[u], acc[a], 0, 0, 0);
+                else if constexpr (PATTERN == 1) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[(u + 3 * a) & 3], acc[a], 0, 0, 0);
+                else if constexpr (PATTERN == 2) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc[a], 0, 0, 0);
+                else if constexpr (PATTERN == 3) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(u + a) & 3]), __builtin_bit_cast(bf16x8, B[u]), acc[a], 0, 0, 0);
+                else acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)(0x3f000000u | (__builtin_bit_cast(unsigned short, A[(u + a) & 3][0]) << 7))),
+                                                                   __builtin_bit_cast(float, (unsigned)(0x3f000000u | (__builtin_bit_cast(unsigned short, B[u][1]) << 7))), acc[a], 0, 0, 0);
+            }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -73,9 +80,10 @@ static void run(const char* label, const f16x8* d_ops, int ncu) {
         clk_mhz = acc / ncu;                                      // last repetition: the settled clock
     }
     const double mfma = (double)iters * 16 * 4 * WAVES * ncu;     // per SIMD x 4 SIMDs x CUs
-    const double flop = mfma * 32768.0;
-    printf("%-8s waves/SIMD=%d : %8.3f ms (worst of 5: %8.3f)  %7.1f TFLOP/s  = %.3f of 2500 dense peak   shader clock %.0f MHz  "
-           "(%.2f cycles per MFMA per SIMD)\n", label, WAVES, best, worst, flop / (best * 1e-3) / 1e12, flop / (best * 1e-3) / 2.5e15, clk_mhz,
+    const double flop = mfma * (PATTERN == 4 ? 4096.0 : 32768.0);
+    const double peak = PATTERN == 4 ? 157.3e12 : 2.5e15;
+    printf("%-8s waves/SIMD=%d : %8.3f ms (worst of 5: %8.3f)  %7.1f TFLOP/s  = %.3f of %.1f dense peak   shader clock %.0f MHz  "
+           "(%.2f cycles per MFMA per SIMD)\n", label, WAVES, best, worst, flop / (best * 1e-3) / 1e12, flop / (best * 1e-3) / peak, peak / 1e12, clk_mhz,
            best * 1e-3 * clk_mhz * 1e6 / ((double)iters * 16 * WAVES));
     hipFree(d_out); hipFree(d_clk);
 }
@@ -90,7 +98,7 @@ int main() {
         srand(12345);
         for (auto& v : h) {
             const float r = (float)rand() / RAND_MAX * 2.f - 1.f;  // uniform (-1, 1): full-width fp16 mantissas, zero mean
-            v = (_Float16)(pass == 0 ? 0.f : r);
+            v = (_Float16)(pass == 0 ? 0.f : r);      // (pass 0: "zero f32" still has the constant exponent bits: 0.5 x 0.5)
         }
         hipMemcpy(d_ops, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice);
         run<1>(pass == 0 ? "zeros" : "random", d_ops, ncu);
@@ -98,6 +106,10 @@ int main() {
         if (pass == 1) {
             run<2, 1>("rnd A+B", d_ops, ncu);          // both operands change at every MFMA
             run<2, 2>("rnd fix", d_ops, ncu);          // the same random operands at every MFMA
+            run<2, 3>("rnd bf16", d_ops, ncu);         // v_mfma_f32_32x32x16_bf16, the same bit patterns read as bf16
+            run<2, 4>("rnd f32", d_ops, ncu);          // v_mfma_f32_32x32x2_f32, random mantissas in [0.5, 1)
+        } else {
+            run<2, 4>("zero f32", d_ops, ncu);
         }
     }
     return 0;
