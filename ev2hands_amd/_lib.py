@@ -126,7 +126,7 @@ def lib() -> C.CDLL:
     L.ev2h_transpose_logits.argtypes = [vp, ci, ci, vp, C.c_size_t, vp]
     L.ev2h_sa_mlp_max.argtypes = [C.POINTER(SaDesc), vp]
     L.ev2h_fp_mlp.argtypes = [C.POINTER(FpDesc), vp]
-    L.ev2h_tile_geometry.argtypes = [ci, ci, ci, ci, C.c_int * 8]
+    L.ev2h_tile_geometry.argtypes = [ci, ci, ci, ci, C.c_int * 10]
     L.ev2h_attn_sim.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, vp, vp]
     L.ev2h_attn_context.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, vp, vp]
     L.ev2h_attn_sim_folded_scratch.restype = C.c_size_t

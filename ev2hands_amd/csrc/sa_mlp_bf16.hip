@@ -82,6 +82,19 @@ struct SaBCfg {
     static constexpr int RES_LDS_BYTES = RES_W + SMALL;
     static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
+    // F16X2 with 1..4 channels left over after the last full 32-channel tile (C2 = 196: channels 192..195): the three plane
+    // products of those channels share MFMAs instead of taking three each (pack.py builds the matching images):
+    //  * layer 2, last tile: rows 8..11 of the tile's HIGH-plane image hold the LOW plane of rows 0..3, so (A = high image,
+    //    B = xh) yields wh*xh in D rows 0..3 and wl*xh in rows 8..11 -- the separate (wl, xh) MFMA is dropped and rows 8..11 are
+    //    added to rows 0..3 in registers (same lane: D rows 8..11 are registers 4..7 of the lower half-wave);
+    //  * layer 3, last 16-slot k-block (4 live slots): the slots carry [xh | xl | xh | 0] against [wh | wh | wl | 0] -- ONE MFMA
+    //    instead of three.
+    // 24 of the 480 MFMAs of a 128-196-256 strip (5 %) disappear; the products are the same three (plus wl*xl in layer 2).
+#ifdef EV2H_NO_PACK4
+    static constexpr bool PACK4 = false;
+#else
+    static constexpr bool PACK4 = (NS == 2) && REM >= 1 && REM <= 4;
+#endif
 };
 
 // RES = false: weight tiles are streamed, two LDS buffers, one barrier per tile (any MLP width).
@@ -349,8 +362,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 }
 #pragma unroll
                 for (int j = 0; j < PL::NPROD; ++j) {
-                    h2[t0] = mfma_planes<NS>(a0[PL::A[j]], bp[m0][PL::B[j]], h2[t0]);
-                    h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
+                    // PACK4: the last tile's high-plane image carries its low plane in rows 8..11 (see SaBCfg)
+                    if (!(Cfg::PACK4 && t0 == T2 - 1 && PL::A[j] == 1)) h2[t0] = mfma_planes<NS>(a0[PL::A[j]], bp[m0][PL::B[j]], h2[t0]);
+                    if (!(Cfg::PACK4 && t1 == T2 - 1 && PL::A[j] == 1)) h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
                 }
             }
             if constexpr (ROWS) {
@@ -368,6 +382,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
 
         STAMP(38);
+        if constexpr (Cfg::PACK4) {          // wl*xh of the leftover channels arrived in D rows 8..11 = registers 4..7
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h2[T2 - 1][r] += h2[T2 - 1][r + 4]; h2[T2 - 1][r + 4] = 0.f; }
+        }
         // ReLU in fp32 (the bias is already in), then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
         u32x4 h2p[NS][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
 #pragma unroll
@@ -380,6 +398,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
+        }
+        if constexpr (Cfg::PACK4) {
+            // last k-block: slots [xh(4) | xl(4)] in the lower half-wave, [xh(4) | 0] in the upper one (which gets the values from
+            // its partner lane: same neighbour, other half); pack.py stores [wh | wh | wl | 0] at these positions of the W3 image
+            const unsigned h01 = h2p[0][T2 - 1][0][0], h23 = h2p[0][T2 - 1][0][1];
+            const unsigned l01 = h2p[1][T2 - 1][0][0], l23 = h2p[1][T2 - 1][0][1];
+            const unsigned ph01 = (unsigned)__shfl_xor((int)h01, 32, 64), ph23 = (unsigned)__shfl_xor((int)h23, 32, 64);
+            h2p[0][T2 - 1][0][0] = half ? ph01 : h01;
+            h2p[0][T2 - 1][0][1] = half ? ph23 : h23;
+            h2p[0][T2 - 1][0][2] = half ? 0u : l01;
+            h2p[0][T2 - 1][0][3] = half ? 0u : l23;
         }
         STAMP(39);
 
@@ -429,6 +458,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
 #pragma unroll
                         for (int j = 0; j < PL::NPROD; ++j) {
+                            if (Cfg::PACK4 && t == T2 - 1 && !(PL::A[j] == 0 && PL::B[j] == 0)) continue;   // one MFMA holds all three products
                             if constexpr (TPS == 2) {
                                 acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
                                 acc1 = mfma_planes<NS>(a[PL::A[j]], w1[PL::B[j]], acc1);
@@ -583,13 +613,14 @@ static int dispatch_fp(const SaBP& p, const ev2h_fp_desc* d, hipStream_t st) {
 int ev2h_gemm_tile_geometry(int ns, int out[2]);
 namespace {
 template <int C1, int C2, int C3, int NS>
-int fill_geometry(int out[8]) {
+int fill_geometry(int out[10]) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     out[0] = Cfg::T2; out[1] = Cfg::C2P; out[2] = Cfg::RS2; out[3] = Cfg::RS3; out[4] = Cfg::TB2; out[5] = Cfg::TB3;
+    out[8] = Cfg::PACK4 ? Cfg::REM : 0;
     return EV2H_OK;
 }
 template <int NS>
-int geometry_ns(int c1, int c2, int c3, int out[8]) {
+int geometry_ns(int c1, int c2, int c3, int out[10]) {
     if (c1 == 32 && c2 == 32 && c3 == 64) return fill_geometry<32, 32, 64, NS>(out);
     if (c1 == 64 && c2 == 64 && c3 == 128) return fill_geometry<64, 64, 128, NS>(out);
     if (c1 == 64 && c2 == 96 && c3 == 128) return fill_geometry<64, 96, 128, NS>(out);
@@ -600,9 +631,9 @@ int geometry_ns(int c1, int c2, int c3, int out[8]) {
 }
 }  // namespace
 
-extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[8]) {
+extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10]) {
     EV2H_CHECK_ARG(out && planes >= 1 && planes <= 3);
-    for (int i = 0; i < 8; ++i) out[i] = 0;
+    for (int i = 0; i < 10; ++i) out[i] = 0;
     const int rc = planes == 1 ? geometry_ns<1>(C1, C2, C3, out) : planes == 2 ? geometry_ns<2>(C1, C2, C3, out) : geometry_ns<3>(C1, C2, C3, out);
     if (rc) { ev2h_set_error("ev2h_tile_geometry: unsupported chain %d-%d-%d", C1, C2, C3); return rc; }
     return ev2h_gemm_tile_geometry(planes, out + 6);

@@ -106,9 +106,9 @@ def sa_bf16_geometry(C2: int):
 def kernel_geometry(C1: int, C2: int, C3: int, ns: int) -> dict:
     """Tile-image geometry of a chain as the KERNELS define it (ev2h_tile_geometry: csrc/sa_mlp_bf16.hip SaBCfg, csrc/gemm_bf16.hip
     GBCfg) -- the one source of truth the image builders below are asserted against."""
-    out = (C.c_int * 8)()
+    out = (C.c_int * 10)()
     _lib.check(_lib.lib().ev2h_tile_geometry(C1, C2, C3, ns, out), "ev2h_tile_geometry")
-    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK"), out))
+    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK", "LEFTOVER"), out))
 
 
 def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
@@ -121,8 +121,14 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     C2, C1 = W2.shape
     C3 = W3.shape[0]
     T2, C2P = sa_bf16_geometry(C2)
+    g = kernel_geometry(C1, C2, C3, ns)
+    left = g["LEFTOVER"]               # 0, or the 1..4 channels past the last full tile whose plane products share MFMAs (SaBCfg::PACK4)
+    base = 32 * (T2 - 1)
     W2p = _pad(W2, T2 * 32, C1)
     p2 = split_bf16_planes(W2p, ns)
+    if left:
+        assert ns == 2 and C2 - base == left and left <= 4
+        p2[0][base + 8:base + 8 + left] = p2[1][base:base + left]        # rows 8.. of the high-plane image: the leftover rows' LOW plane
     rs2 = ns * 64 + 16
     img2 = np.zeros((C1 // 32, T2 * 32, rs2), dtype=np.uint8)
     for c in range(C1 // 32):
@@ -138,12 +144,16 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     ok = ch < C2
     W3p[:, ok] = W3[:, ch[ok]]
     p3 = split_bf16_planes(W3p, ns)
+    if left:                                                              # last 16 k-slots of every row: [wh | wh | wl | 0]
+        wh, wl = p3[0][:, base:base + 4].copy(), p3[1][:, base:base + 4].copy()      # (positions base..base+3 <-> channels base..base+3)
+        p3[0][:, base + 4:base + 8] = wh
+        p3[0][:, base + 8:base + 12] = wl
+        p3[0][:, base + 12:base + 16] = 0
     rs3 = ns * C2P * 2 + 16
     img3 = np.zeros((C3 // 32, 32, rs3), dtype=np.uint8)
     for s_ in range(ns):
         blk = p3[s_].view(np.uint8).reshape(C3 // 32, 32, C2P * 2)
         img3[:, :, s_ * C2P * 2:(s_ + 1) * C2P * 2] = blk
-    g = kernel_geometry(C1, C2, C3, ns)
     mine = {"T2": T2, "C2P": C2P, "RS2": rs2, "RS3": rs3, "TB2": img2[0].size, "TB3": img3[0].size}
     if any(g[k] != v for k, v in mine.items()):
         raise _lib.Ev2hError(f"tile geometry of chain {C1}-{C2}-{C3} (planes {ns}): pack.py builds {mine}, the kernels expect {g}")

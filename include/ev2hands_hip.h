@@ -227,10 +227,13 @@ int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
 /* Geometry of the host-packed weight tile images (W2s / W3s of ev2h_sa_desc and ev2h_fp_desc, Ws of ev2h_gemm_desc) for a chain
  * (C1, C2, C3) and `planes` operand planes (1 BF16, 2 F16X2, 3 BF16X3), straight from the kernels' compile-time configuration:
  * out = { T2 (32-row layer-2 tiles), C2P (layer-3 contraction length in the permuted order), RS2, RS3 (bytes per LDS row of a
- * W2 / W3 tile), TB2, TB3 (bytes per tile), GEMM RS (bytes per row of a dense W image tile), GEMM BK (k columns per tile) }.
+ * W2 / W3 tile), TB2, TB3 (bytes per tile), GEMM RS (bytes per row of a dense W image tile), GEMM BK (k columns per tile),
+ * LEFTOVER (0, or the 1..4 channels beyond the last full 32-channel tile whose plane products share MFMAs: the images then carry,
+ * in the HIGH plane, the low plane of the leftover W2 rows in rows 8..11 of the last tile and [wh | wh | wl | 0] in the last 16
+ * k-slots of every W3 row -- csrc/sa_mlp_bf16.hip SaBCfg::PACK4), 0 }.
  * A host packer asserts its own layout against this (ev2hands_amd/pack.py does at load time), so the kernels and the packer
  * cannot drift apart silently.  Needs no GPU. */
-int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[8]);
+int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10]);
 
 /* ---- attention (model/TEHNet.py:13-27) ------------------------------------------------------------ */
 /* sim[b][h][c][d] = softmax_c( 256^-0.5 * sum_n logits[b][n][c] * query_h[b][n][d] ); query of hand h

@@ -178,9 +178,10 @@ def test_tile_geometry_comes_from_the_kernels(built):
     test.  No GPU needed."""
     import ctypes as C
     from ev2hands_amd import pack
-    out = (C.c_int * 8)()
+    out = (C.c_int * 10)()
     assert built.ev2h_tile_geometry(128, 196, 256, 2, out) == 0
-    assert list(out) == [7, 208, 144, 848, 7 * 32 * 144, 32 * 848, 144, 32]
+    assert list(out) == [7, 208, 144, 848, 7 * 32 * 144, 32 * 848, 144, 32, 4, 0]     # 4 leftover channels share MFMAs (f16x2 only)
+    assert built.ev2h_tile_geometry(128, 196, 256, 3, out) == 0 and out[8] == 0
     assert built.ev2h_tile_geometry(100, 100, 100, 2, out) != 0 and b"unsupported chain" in built.ev2h_last_error()
     rng = np.random.default_rng(0)
     for (c1, c2, c3) in ((32, 32, 64), (64, 96, 128), (128, 196, 256), (256, 256, 32)):
