@@ -332,7 +332,6 @@ def run_rank(a) -> int:
     import torch
     from ev2hands_amd import dist as evdist, synth
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")          # before the first HIP call of this process (see ev2h_init below)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -354,7 +353,7 @@ def run_rank(a) -> int:
         # torch.distributed / RCCL create dozens of streams; when the forward's side stream was created after them it landed on
         # the main stream's queue and the two-stream overlaps silently vanished: that, not the gather, was the "4-5 % multi-GPU
         # overhead at world size 1" of round 2 (profiles/r3_dist_overhead.txt).  So: the library's side stream is created FIRST
-        # (ev2h_init), and the process asks for 8 hardware queues (read by the HIP runtime when it initialises).
+        # (ev2h_init), with the runtime's default number of hardware queues (asking for 8 made the 1-rank RCCL step 10 % slower).
         from ev2hands_amd import _lib as _early
         _early.check(_early.lib().ev2h_init(), "ev2h_init")
     if use_dist:
@@ -415,20 +414,27 @@ def run_rank(a) -> int:
                     out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
                 return out
 
-    # multi-GPU: the forward writes its windows straight into this rank's slice of the persistent gather buffer (ev2h_outputs'
-    # window strides), then ONE in-place all-gather -- no packing copy, no allocation per step
-    gbuf = evdist.GatherBuffer(N, gB, dev) if use_dist else None
+    # multi-GPU: the forward writes its windows straight into this rank's slice of a persistent gather buffer (ev2h_outputs'
+    # window strides), then ONE in-place all-gather -- no packing copy, no allocation per step.  Two buffers alternate and the
+    # gather is asynchronous: the xGMI transfer of step i runs under the forward of step i+1 (EV2H_BENCH_SYNC_GATHER=1: in
+    # stream order).  The last gather completes inside the timed region (sync() drains the pipeline).
+    sync_gather = bool(os.environ.get("EV2H_BENCH_SYNC_GATHER"))
+    pipe = evdist.GatherPipeline(N, gB, dev, depth=1 if sync_gather else 2) if use_dist else None
 
     def step():
-        if gbuf is None:
+        if pipe is None:
             return forward()
+        rows = pipe.rows()
         if a.stub:
-            gbuf.rows().copy_(evdist.pack_outputs(forward()))
+            rows.copy_(evdist.pack_outputs(forward()))
         else:
-            forward(gbuf.rows())
-        return gbuf.gather()
+            forward(rows)
+        pending = pipe.submit()
+        return pending.result() if sync_gather else pending
 
     def sync():
+        if pipe is not None:
+            pipe.drain()
         if use_dist:
             dist.barrier()
         if not a.stub:
@@ -499,10 +505,13 @@ def run_rank(a) -> int:
                                       "for the pair search)" if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
-                       "parallelism": f"batch-shard x{world}" + (" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer)" if use_dist else "")},
+                       "parallelism": f"batch-shard x{world}" + ((" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer; " +
+                                                                       ("in stream order)" if sync_gather else "asynchronous, overlapped with the next forward)")) if use_dist else "")},
         }
         if a.stub:
             res["stub"] = True
+            if last is not None and not isinstance(last, dict):
+                last = last.result()
             res["gathered_rows"] = int(last["class_logits"].shape[0]) if last is not None else None
             res["gathered_rank_ids"] = sorted({int(v) for v in last["class_logits"][:, 0, 0].tolist()}) if last is not None else None
         else:

@@ -102,6 +102,10 @@ static SideCtx* side_ctx() {     // the current device's side stream, or nullptr
     if (c.state == 0) {
         const char* e = getenv("EV2H_TWO_STREAMS");
         c.state = -1;
+        // A NORMAL-priority, non-blocking stream, created as early as possible (ev2h_init).  Measured alternatives, 1-rank RCCL
+        // process, B = 256 (profiles/r3_dist_overhead.txt): a low- or high-priority side stream (its own queue class): -12 %;
+        // GPU_MAX_HW_QUEUES=8 with the side stream created first: -10 % (more hardware queues than the scheduler maps at once);
+        // side stream created after torch's / RCCL's streams with the default 4 queues: -5 % (it shares the caller's queue).
         if (!(e && atoi(e) == 0) && hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) == hipSuccess) {
             bool ok = true;
             for (int i = 0; i < SideCtx::NEV; ++i) ok = ok && hipEventCreateWithFlags(&c.ev[i], hipEventDisableTiming) == hipSuccess;

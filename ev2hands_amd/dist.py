@@ -117,3 +117,64 @@ class GatherBuffer:
         if min(self.sizes) == self.big:
             return unpack_outputs(self.full, self.N)
         return unpack_outputs(torch.cat([self.full[r * self.big:r * self.big + self.sizes[r]] for r in range(self.world)], 0), self.N)
+
+
+class GatherPipeline:
+    """Ping-pong of `depth` GatherBuffers for back-to-back steps: the all-gather of step i is issued with async_op=True and runs on
+    RCCL's stream while the forward of step i+1 already executes on the caller's -- the xGMI transfer (7 x 13.4 MB arriving per
+    rank at world 8; ring collectives are per-link bound) is hidden under compute instead of being added to every step; the
+    forward of step i+depth waits for gather i before it overwrites that buffer.
+
+        pipe = GatherPipeline(N, global_B, device)
+        for batch in batches:
+            net.net(batch, net.hands, rows=pipe.rows())     # waits only for the gather that last used this buffer
+            pending = pipe.submit()                         # all-gather in flight
+            ...
+            outputs = pending.result()                      # the caller's stream now waits for the collective; views of the buffer
+    `result()` must be taken before the buffer comes round again (depth steps later): a later rows() raises otherwise."""
+
+    class Pending:
+        def __init__(self, buf, work):
+            self.buf, self.work, self._out, self.consumed = buf, work, None, False
+
+        def wait(self):
+            if self.work is not None:
+                self.work.wait()                            # device-side: the current stream waits for the collective
+                self.work = None
+
+        def result(self) -> dict:
+            self.wait()
+            self.consumed = True
+            if self._out is None:
+                b = self.buf
+                if min(b.sizes) == b.big:
+                    self._out = unpack_outputs(b.full, b.N)
+                else:
+                    self._out = unpack_outputs(torch.cat([b.full[r * b.big:r * b.big + b.sizes[r]] for r in range(b.world)], 0), b.N)
+            return self._out
+
+    def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        self.bufs = [GatherBuffer(N, global_batch, device, group) for _ in range(depth)]
+        self.pending = [None] * depth
+        self.i = 0
+
+    def rows(self) -> torch.Tensor:
+        p = self.pending[self.i]
+        if p is not None:
+            p.wait()                                        # the gather that read this buffer must be done before it is overwritten
+        return self.bufs[self.i].rows()
+
+    def submit(self) -> "GatherPipeline.Pending":
+        b = self.bufs[self.i]
+        lo = b.rank * b.big
+        work = dist.all_gather_into_tensor(b.full, b.full[lo:lo + b.big], group=b.group, async_op=True)
+        p = self.pending[self.i] = GatherPipeline.Pending(b, work)
+        self.i = (self.i + 1) % len(self.bufs)
+        return p
+
+    def drain(self) -> None:
+        for p in self.pending:
+            if p is not None:
+                p.wait()

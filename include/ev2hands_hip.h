@@ -62,7 +62,8 @@ const char* ev2h_last_error(void);
  * ev2h_forward forks onto).  Idempotent; ev2h_forward calls it itself.  Call it EARLY in a process that will create many HIP
  * streams (torch's stream pool, RCCL): HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and streams
  * that share one execute in order -- a side stream created late can land on the caller's queue, which silently removes the
- * two-stream overlaps (~5 % of a B = 256 step).  Setting GPU_MAX_HW_QUEUES=8 in the environment has the same effect. */
+ * two-stream overlaps (~5 % of a B = 256 step).  (Raising GPU_MAX_HW_QUEUES is no substitute: 8 queues cured the late-creation case
+ * but cost 10 % when the side stream was created first.) */
 int ev2h_init(void);
 /* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp]. */
 void ev2h_struct_sizes(size_t out[7]);

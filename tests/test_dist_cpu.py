@@ -69,7 +69,46 @@ def _worker_inplace(rank, world, port, gB, N, q, steps=2):
     dist.destroy_process_group()
 
 
+def _worker_pipeline(rank, world, port, gB, N, q, steps=5):
+    """GatherPipeline: the gather of step i is in flight while step i+1's 'forward' already writes the other buffer; every step's
+    result must still be that step's, and a buffer is only overwritten after its gather completed."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = evdist.shard_range(gB, rank, world)
+    pipe = evdist.GatherPipeline(N, gB, "cpu", depth=2)
+    ok, handles = True, []
+    for step in range(steps):
+        pipe.rows().copy_(evdist.pack_outputs(_fake_outputs(lo + 100 * step, hi + 100 * step, N)))
+        handles.append((step, pipe.submit()))
+        if len(handles) == 2:                              # consume one step late: the next forward has already been "enqueued"
+            st, h = handles.pop(0)
+            full, want = h.result(), _fake_outputs(100 * st, gB + 100 * st, N)
+            ok = ok and torch.equal(full["class_logits"], want["class_logits"]) and torch.equal(full["right"]["vertices"], want["right"]["vertices"])
+    pipe.drain()
+    for st, h in handles:
+        full, want = h.result(), _fake_outputs(100 * st, gB + 100 * st, N)
+        ok = ok and torch.equal(full["class_logits"], want["class_logits"]) and torch.equal(full["left"]["j3d"], want["left"]["j3d"])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
 import pytest
+
+
+@pytest.mark.parametrize("gB", [6, 7])
+def test_gather_pipeline_world2(gB):
+    world, N = 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, world, port, gB, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
 
 
 @pytest.mark.parametrize("gB", [6, 7, 1])
