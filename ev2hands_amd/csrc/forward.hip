@@ -581,7 +581,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
                             float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
                             void* workspace, size_t workspace_bytes, ev2h_stream_t st) {
     EV2H_CHECK_ARG(w && xyz_cm && fps_init && out && workspace);
-    EV2H_CHECK_ARG(B > 0 && N >= 128 && N <= 8192 && (C == 4 || C == 5));    // size contract: see ev2hands_hip.h
+    EV2H_CHECK_ARG(B > 0 && N >= 128 && N <= 32768 && (C == 4 || C == 5));    // size contract: see ev2hands_hip.h
     EV2H_CHECK_ARG(out->class_logits && out->params[0] && out->params[1]);
     // a NULL hand model skips that hand's MANO layer (the caller applies its own to params[h], TEHNet.py:103)
     EV2H_CHECK_ARG(!mano_left || (out->vertices[0] && out->joints[0]));

@@ -57,11 +57,15 @@ struct FpsJobs {
     float4* ctr[3];
 };
 
-template <int PPT>
-__global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts4, int N, FpsJobs jobs) {
+// THREADS = 256 with the window's points also in LDS (N <= 8192: the winner's coordinates are one LDS read away); windows beyond
+// that -- the reference has no upper limit -- take THREADS = 1024, PPT <= 32 (N <= 32768) and read the winner from global memory
+// (LDS_PTS = false: 32768 points would need 512 KB).
+template <int PPT, int THREADS = 256, bool LDS_PTS = true>
+__global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__ pts4, int N, FpsJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* spts = reinterpret_cast<float4*>(smem_raw);
-    __shared__ unsigned long long skey[2][4];
+    constexpr int NW = THREADS / 64;
+    __shared__ unsigned long long skey[2][NW];
 
     const int b = blockIdx.x;
     const int job = blockIdx.y;
@@ -72,9 +76,9 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
     float px[PPT], py[PPT], pz[PPT], md[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 256 + tid;
+        const int p = j * THREADS + tid;
         float4 v = (p < N) ? src[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < N) spts[p] = v;
+        if (LDS_PTS && p < N) spts[p] = v;
         px[j] = v.x; py[j] = v.y; pz[j] = v.z;
         md[j] = 1e10f;
     }
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
     float4* octr = jobs.ctr[job] + (size_t)b * S;
 
     for (int i = 0; i < S; ++i) {
-        const float4 c = spts[far];
+        const float4 c = LDS_PTS ? spts[far] : src[far];
         if (tid == 0) { oidx[i] = far; octr[i] = c; }
         unsigned long long best = 0ull;
         if constexpr (PPT >= 2) {
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
                 const f32x2 d = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int p = (j + e) * 256 + tid;
+                    const int p = (j + e) * THREADS + tid;
                     if (d[e] < md[j + e]) md[j + e] = d[e];
                     const unsigned long long key =
                         ((unsigned long long)__float_as_uint(md[j + e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
         } else {
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
-                const int p = j * 256 + tid;
+                const int p = j * THREADS + tid;
                 const float dx = __fsub_rn(px[j], c.x), dy = __fsub_rn(py[j], c.y), dz = __fsub_rn(pz[j], c.z);
                 const float d = sqnorm3(dx, dy, dz);
                 if (d < md[j]) md[j] = d;
@@ -121,10 +125,9 @@ __global__ __launch_bounds__(256) void fps_kernel(const float4* __restrict__ pts
         best = wave_max_u64_dpp(best);
         if (lane == 0) skey[i & 1][wave] = best;
         __syncthreads();
-        unsigned long long k0 = skey[i & 1][0], k1 = skey[i & 1][1], k2 = skey[i & 1][2], k3 = skey[i & 1][3];
-        k0 = k0 > k1 ? k0 : k1;
-        k2 = k2 > k3 ? k2 : k3;
-        k0 = k0 > k2 ? k0 : k2;
+        unsigned long long k0 = skey[i & 1][0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const unsigned long long kw = skey[i & 1][w]; k0 = k0 > kw ? k0 : kw; }
         far = (int)(0xffffffffu - (unsigned)(k0 & 0xffffffffull));
     }
 }
@@ -140,6 +143,8 @@ struct BallArgs {
 
 constexpr int BALL_CTR_PER_WG = 32, BALL_UNR = 4;
 
+// LDS_PTS = false (N > 8192: the window does not fit LDS): the points are read from global memory (L2-resident, coalesced)
+template <bool LDS_PTS>
 __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restrict__ pts4, const float4* __restrict__ ctr4,
                                                          int N, int S, BallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -147,8 +152,10 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* src = pts4 + (size_t)b * N;
-    for (int p = tid; p < N; p += 256) spts[p] = src[p];
-    __syncthreads();
+    if constexpr (LDS_PTS) {
+        for (int p = tid; p < N; p += 256) spts[p] = src[p];
+        __syncthreads();
+    }
 
     const int s_begin = blockIdx.x * BALL_CTR_PER_WG;
     for (int s = s_begin + wave; s < s_begin + BALL_CTR_PER_WG && s < S; s += 4) {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
 #pragma unroll
             for (int u = 0; u < BALL_UNR; ++u) {
                 const int p = base + 64 * u + lane;
-                const float4 q = spts[p < N ? p : N - 1];
+                const float4 q = LDS_PTS ? spts[p < N ? p : N - 1] : src[p < N ? p : N - 1];
                 // square_distance (pointnet2_utils.py:37-39): -2*(c.q) + |c|^2 + |q|^2, dot as an fma chain
                 const float dot = __fmaf_rn(c.z, q.z, __fmaf_rn(c.y, q.y, __fmul_rn(c.x, q.x)));
                 d[u] = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), c.w), q.w);
@@ -302,7 +309,7 @@ extern "C" int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, 
 extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init,
                               int32_t* const* idx, float* const* ctr4, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts4 && S && init && idx && ctr4);
-    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 8192 && njobs >= 1 && njobs <= 3);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 32768 && njobs >= 1 && njobs <= 3);
     FpsJobs jobs{};
     jobs.njobs = njobs;
     for (int j = 0; j < njobs; ++j) {
@@ -316,7 +323,7 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t st = (hipStream_t)stream;
     const float4* p = (const float4*)pts4;
-    if (N > 2048) {   // > 32 KiB of points: raise the dynamic-LDS limit once
+    if (N > 2048 && N <= 8192) {   // > 32 KiB of points: raise the dynamic-LDS limit once
         static PerDevice attr_set{};
         EV2H_ONCE_PER_DEVICE(attr_set,
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>),
@@ -329,7 +336,9 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     else if (N <= 1024) fps_kernel<4><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 2048) fps_kernel<8><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 4096) fps_kernel<16><<<grid, 256, lds, st>>>(p, N, jobs);
-    else fps_kernel<32><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 8192) fps_kernel<32><<<grid, 256, lds, st>>>(p, N, jobs);
+    else if (N <= 16384) fps_kernel<16, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);      // beyond the LDS-resident sizes
+    else fps_kernel<32, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
@@ -342,7 +351,7 @@ extern "C" int ev2h_fps(const float* pts4, int B, int N, int S, const int64_t* i
 extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const double* radius,
                                const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts4 && ctr4 && radius && nsample && gidx);
-    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 8192 && S > 0 && nrad >= 1 && nrad <= 3);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 32768 && S > 0 && nrad >= 1 && nrad <= 3);
     BallArgs a{};
     a.nrad = nrad;
     for (int i = 0; i < nrad; ++i) {
@@ -354,14 +363,19 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     }
     a.cnt = cnt;
     dim3 grid(ceil_div(S, BALL_CTR_PER_WG), B);
+    if (N > 8192) {
+        ball_query_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
+        EV2H_CHECK_LAUNCH();
+        return EV2H_OK;
+    }
     if (N > 4096) {
         static PerDevice attr_set{};
         EV2H_ONCE_PER_DEVICE(attr_set,
-            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel),
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16)););
     }
-    ball_query_kernel<<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
-                                                                                       N, S, a);
+    ball_query_kernel<true><<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
+                                                                                             N, S, a);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -407,12 +407,13 @@ size_t ev2h_workspace_bytes(int B, int N);
 /* TEHNet.forward, model/TEHNet.py:168-197, for B windows of N points with C channels.
  * fps_init: device int64 [4][B] in the reference's RNG consumption order (enc.sa1, enc.sa2,
  * left.sa1, right.sa1).  workspace: device buffer of at least ev2h_workspace_bytes(B, N).
- * Size contract: 128 <= N <= 8192 points per window, B limited by the workspace only.  Below 128 the reference itself fails
+ * Size contract: 128 <= N <= 32768 points per window, B limited by the workspace only.  Below 128 the reference itself fails
  * (query_ball_point indexes an N-column tensor with an nsample = 128 column mask, pointnet2_utils.py:103-106: IndexError).  It has
- * no upper limit, but materialises [B, S, N] int64 index tensors (8.4 MB per window and stage at N = 2048); 8192 is
- * BASELINE.json's dense-window configuration and 4x the reference's operating point -- the selection kernels keep a window's
- * points in registers / LDS.  ev2h_event_window_build takes at most 32768 raw events per window (LDS sort; the reference's
- * windows are 2048 events, erpc.py:170, or a few thousand, evaluation_stream.py:124-146).
+ * no upper limit, but materialises [B, S, N] int64 index tensors (8.4 MB per window and stage at N = 2048, 134 MB at 32768).  Up to
+ * 8192 points (BASELINE.json's dense-window configuration, 4x the reference's operating point) the selection kernels keep a window's
+ * points in registers / LDS; from 8193 to 32768 they run 1024-thread / global-memory variants (same arithmetic, same results).
+ * ev2h_event_window_build takes at most 32768 raw events per window (LDS sort; the reference's windows are 2048 events,
+ * erpc.py:170, or a few thousand, evaluation_stream.py:124-146).
  * mano_left / mano_right may be NULL: that hand's MANO layer is skipped (out->vertices / joints of the hand are not touched)
  * and the caller applies its own hand model to out->params, as TEHNet.py:103 allows any callable. */
 int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,

@@ -120,7 +120,7 @@ def check_against(out, net, ref, trace, B, N):
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 @pytest.mark.parametrize("kind,C,N,B,seed", [("U", 4, 2048, 2, 0), ("E", 5, 2048, 2, 1), ("E", 4, 2048, 3, 4), ("U", 5, 256, 2, 2),
-                                              ("E", 4, 8192, 1, 5), ("U", 5, 1000, 2, 6), ("E", 4, 128, 1, 7), ("U", 4, 640, 5, 8),
+                                              ("E", 4, 8192, 1, 5), ("E", 5, 16384, 1, 9), ("U", 5, 1000, 2, 6), ("E", 4, 128, 1, 7), ("U", 4, 640, 5, 8),
                                               # odd sizes: partial 32-row strips in the row-chain kernels, ragged 256-point partial sums of
                                               # the folded attention, an odd point count, one point past a power of two
                                               ("E", 4, 333, 3, 9), ("U", 5, 2049, 1, 10), ("E", 4, 130, 2, 11)])
@@ -299,7 +299,7 @@ def test_window_size_limits_match_the_reference_domain():
     with pytest.raises(_lib.Ev2hError, match="bad argument"):
         net(xyz.cuda())
     with pytest.raises(_lib.Ev2hError, match="bad argument"):
-        net(torch.zeros(1, 4, 8320, device="cuda"))              # > 8192: the documented upper limit of the selection kernels
+        net(torch.zeros(1, 4, 32800, device="cuda"))             # > 32768: the documented upper limit of the selection kernels
 
 
 def test_training_forward_is_refused():

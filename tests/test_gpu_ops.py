@@ -25,7 +25,9 @@ def cloud_xyz(kind, B, N, seed):
     return synth.synth_cloud(kind, B, 4, N, seed)[:, :3].permute(0, 2, 1).contiguous()
 
 
-@pytest.mark.parametrize("kind,N,S", [("U", 2048, 512), ("E", 2048, 128), ("U", 512, 128), ("E", 300, 64), ("U", 8192, 512)])
+@pytest.mark.parametrize("kind,N,S", [("U", 2048, 512), ("E", 2048, 128), ("U", 512, 128), ("E", 300, 64), ("U", 8192, 512),
+                                      # beyond the register / LDS-resident sizes: 1024-thread variants reading the winner from global memory
+                                      ("U", 8193, 64), ("E", 20000, 512), ("U", 32768, 128)])
 def test_fps_indices_exact(kind, N, S):
     _need_gpu()
     from ev2hands_amd import ops
@@ -58,6 +60,8 @@ def test_fps_degenerate_duplicates():
     ("E", 2048, 128, [0.4, 0.8], [64, 128]),
     ("E", 512, 128, [0.4, 0.8], [64, 128]),
     ("U", 300, 40, [0.2], [32]),
+    ("E", 20000, 512, [0.1, 0.2, 0.4], [32, 64, 128]),          # > 8192 points: the variant that reads the cloud from global memory
+    ("U", 32768, 128, [0.05, 0.8], [64, 128]),
 ])
 def test_ball_query_exact(kind, N, S, radii, ks):
     _need_gpu()
