@@ -18,7 +18,7 @@ for prec in f16x2 f32 bf16x3 bf16; do
 done
 export EV2H_TWO_STREAMS=0
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_f16x2_ss -o bench -- python3 $BENCH --precision f16x2 > $O/${TAG}_kt_f16x2_ss.log 2>&1
-python tools/rocpd_summary.py $(ls $O/${TAG}_kt_f16x2_ss/*/*.db $O/${TAG}_kt_f16x2_ss/*.db 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats_f16x2_single_stream.txt 2>&1
+python tools/rocpd_summary.py $(ls $O/${TAG}_kt_f16x2_ss/*/*.db $O/${TAG}_kt_f16x2_ss/*.db 2>/dev/null | head -1) --sites "128, 196, 256" 3 > $O/${TAG}_bench_kernel_stats_f16x2_single_stream.txt 2>&1
 unset EV2H_TWO_STREAMS
 for prec in f16x2 bf16 f32; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch_$prec -o p -- python3 $SMALL --precision $prec > $O/${TAG}_pmc_fetch_$prec.log 2>&1
