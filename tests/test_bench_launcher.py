@@ -34,6 +34,16 @@ def test_direct_invocation_launches_its_own_ranks():
     assert "roofline" not in d and "cpu_baseline" not in d                     # a stub line can never pass for a measurement
 
 
+def test_in_order_gather_variant_of_the_step():
+    """EV2H_BENCH_SYNC_GATHER=1: one gather buffer, the all-gather in stream order (the default alternates two buffers and issues it
+    asynchronously); both variants must deliver every shard."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "4", "--warmup", "1", "--stub", "--batch", "2", "--points", "128"],
+                       env=dict(_clean_env(), EV2H_BENCH_SYNC_GATHER="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["gathered_rows"] == 4 and d["gathered_rank_ids"] == [0, 1] and "in stream order" in d["config"]["parallelism"]
+
+
 def test_single_rank_stub_line_and_metric_string():
     p = subprocess.run([sys.executable, BENCH, "--steps", "2", "--warmup", "0", "--stub", "--batch", "2", "--points", "256"],
                        env=_clean_env(), capture_output=True, text=True, timeout=600)
