@@ -131,11 +131,12 @@ class GatherPipeline:
             pending = pipe.submit()                         # all-gather in flight
             ...
             outputs = pending.result()                      # the caller's stream now waits for the collective; views of the buffer
-    `result()` must be taken before the buffer comes round again (depth steps later): a later rows() raises otherwise."""
+    A result (views of its buffer) stays valid until that buffer comes round again, `depth` steps later; results nobody asks for
+    cost nothing."""
 
     class Pending:
         def __init__(self, buf, work):
-            self.buf, self.work, self._out, self.consumed = buf, work, None, False
+            self.buf, self.work, self._out = buf, work, None
 
         def wait(self):
             if self.work is not None:
@@ -144,7 +145,6 @@ class GatherPipeline:
 
         def result(self) -> dict:
             self.wait()
-            self.consumed = True
             if self._out is None:
                 b = self.buf
                 if min(b.sizes) == b.big:
