@@ -414,6 +414,8 @@ size_t ev2h_workspace_bytes(int B, int N);
  * points in registers / LDS; from 8193 to 32768 they run 1024-thread / global-memory variants (same arithmetic, same results).
  * ev2h_event_window_build takes at most 32768 raw events per window (LDS sort; the reference's windows are 2048 events,
  * erpc.py:170, or a few thousand, evaluation_stream.py:124-146).
+ * Non-finite inputs or weights are outside the contract ("garbage in, garbage out", as in the reference), but the garbage differs: the
+ * integer-max ReLU of the 16-bit modes maps a NaN with the sign bit set to 0 where torch.relu propagates it.
  * mano_left / mano_right may be NULL: that hand's MANO layer is skipped (out->vertices / joints of the hand are not touched)
  * and the caller applies its own hand model to out->params, as TEHNet.py:103 allows any callable. */
 int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
