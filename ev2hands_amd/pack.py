@@ -273,6 +273,13 @@ def hidden_tensors():
     return T
 
 
+# Layers whose contraction mixes hidden channels with RAW inputs (the group-all set abstractions read [xyz | features],
+# pointnet2_utils.py:155): layer -> the raw input columns.  The hidden tensor that feeds such a layer is anchored as a whole (see
+# equalize_channels): coordinates are O(1), and a checkpoint whose features are 1e6 x larger (with weights 1e-6 x smaller) would
+# otherwise push the coordinates 2^20 below the window's maximum and the feature weights 2^20 below the matrix maximum.
+RAW_COLUMNS = {"sa3.0": slice(0, 3), "left_mano_regressor.sa2.0": slice(0, 3), "right_mano_regressor.sa2.0": slice(0, 3)}
+
+
 def equalize_channels(F: dict, sweeps: int = 3) -> dict:
     """Cross-layer channel equalisation by exact powers of two, in place; returns name -> e [channels] (the accumulated factor
     of every hidden tensor).
@@ -311,7 +318,14 @@ def equalize_channels(F: dict, sweeps: int = 3) -> dict:
             lg = np.zeros(n)
             lg[ok] = 0.5 * (np.log2(om[ok]) - np.log2(r[ok]))
             if ok.any():
-                lg[ok] -= np.median(lg[ok])                  # keep the tensor's overall magnitude where the checkpoint put it
+                lg[ok] -= np.median(lg[ok])                  # keep the tensor's overall magnitude where the checkpoint put it ...
+            for layer, off in consumers:                     # ... unless a consumer mixes it with raw inputs in one contraction:
+                if layer in RAW_COLUMNS and ok.any():        # then the hidden columns are brought level with the raw ones
+                    W = F[layer]["W"]
+                    raw = np.sqrt((W[:, RAW_COLUMNS[layer]] ** 2).sum(0))
+                    hid = np.sqrt((W[:, off:off + n] ** 2).sum(0))[ok] / np.exp2(np.round(lg[ok]))     # column norms after this step
+                    if raw.size and np.median(raw) > 0 and np.median(hid) > 0:
+                        lg[ok] -= np.round(np.log2(np.median(raw) / np.median(hid)))
             e = np.exp2(np.clip(np.round(lg), -40, 40))
             o = 0
             for layer, kind in producers:

@@ -1,0 +1,119 @@
+"""Randomised cross-check of the arithmetic modes on the GPU (no oracle, so hundreds of cases per minute): every case draws a shape
+(B, N, C, cloud kind, MHLNES), a checkpoint (plain / per-channel rescaled / dead channels / heavy-tailed / uniformly rescaled hidden
+activations) and FPS starts, runs the forward in exact fp32 and in f16x2 (and bf16x3 every third case) and requires
+  * every FPS / ball-query / 3-NN selection identical between the modes (they share the selection kernels: a difference would mean
+    a mode touches memory it should not),
+  * every float output within 2e-5 relative of the exact-fp32 mode,
+  * segmentation argmax identical wherever the fp32 top-2 margin exceeds 2e-5 of the logit scale,
+  * a second run of the same case bit-identical (determinism).
+usage: python tools/fuzz_modes.py [ncases] [seed]          prints one line per case and a summary; exit code 1 on any violation."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ev2hands_amd import synth  # noqa: E402
+from ev2hands_amd.model import TEHNetWrapper  # noqa: E402
+
+KEYS = ("vertices", "j3d", "global_orient", "hand_pose", "betas", "transl")
+SEL = ("fps1", "fps2", "fpsmL", "fpsmR", "gidx1_0", "gidx1_2", "gidx2_1", "gidxm0L", "gidxm1R", "nn1_idx", "nn2_idx", "cnt1", "cntmR")
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def run(net, xyz, inits, prec):
+    net.net.precision = prec
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.clone())
+    torch.cuda.synchronize()
+    flat = {"class_logits": out["class_logits"].clone(), **{f"{s}.{k}": out[s][k].clone() for s in ("left", "right") for k in KEYS}}
+    sel = {n: net.net.debug_buffer(n, torch.int32) for n in SEL}
+    return flat, sel
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    worst = 0.0
+    for case in range(ncases):
+        C = int(rng.choice([4, 5]))
+        kind = str(rng.choice(["E", "E", "U", "L"]))
+        B = int(rng.integers(1, 6))
+        N = int(rng.choice([128, 129, 200, 333, 512, 777, 1024, 1500, 2048, 2049, 3000, int(rng.integers(130, 4000))]))
+        if kind == "L":
+            N = min(N, 4096)
+        mh = int(rng.random() < 0.2)
+        seed = int(rng.integers(0, 10 ** 6))
+        variant = str(rng.choice(["plain", "channels", "dead", "heavy", "hidden"]))
+        p1, p2 = float(rng.random()), float(rng.random())         # drawn for every case, so that FUZZ_ONLY replays a case exactly
+        if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != case:
+            continue
+        sd = synth.synth_state_dict(C, seed)
+        if variant == "channels":
+            sd = synth.rescale_channels(sd, [3, 8, 14][int(p1 * 3)], seed, include_l0=p2 < 0.5)
+        elif variant == "dead":
+            sd = synth.rescale_channels(sd, 4, seed, dead_fraction=0.15)
+        elif variant == "heavy":
+            sd = synth.heavy_tailed(sd, [1.0, 2.0][int(p1 * 2)], seed)
+        elif variant == "hidden":
+            sd = synth.rescale_hidden(sd, [1e-4, 1e3, 1e6][int(p1 * 3)])
+        os.environ["ERPC"] = "1" if C == 5 else "0"
+        os.environ["MHLNES"] = str(mh)
+        assets = {s: synth.synth_mano_assets(s, seed % 7) for s in ("left", "right")}
+        net = TEHNetWrapper("cuda:0", mano_assets=assets)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        xyz = synth.synth_cloud(kind, B, C, N, seed).cuda()
+        inits = synth.fps_inits(B, N, seed)
+        ref, rsel = run(net, xyz, inits, "f32")
+        msgs = []
+        truth = None
+        if os.environ.get("FUZZ_ONLY"):                     # diagnosis: the CPU oracle in float64 as the arbiter between the modes
+            from oracle import mano_oracle, tehnet_oracle
+            sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+            hands = mano_oracle.make_hands(assets["left"], assets["right"])
+            with torch.no_grad():
+                o = tehnet_oracle.tehnet_forward(sd, xyz.cpu().clone(), hands, fps_init=inits)
+            truth = {"class_logits": o["class_logits"], **{f"{s_}.{k}": o[s_][k] for s_ in ("left", "right") for k in KEYS}}
+            print("   f32 mode vs fp32 CPU oracle:", {k: f"{rel(ref[k], truth[k]):.1e}" for k in ref})
+        modes = ["f16x2"] + (["bf16x3"] if case % 3 == 0 else [])
+        for prec in modes:
+            got, gsel = run(net, xyz, inits, prec)
+            again, _ = run(net, xyz, inits, prec)
+            for n in SEL:
+                if not torch.equal(gsel[n], rsel[n]):
+                    msgs.append(f"{prec}: selection {n} differs")
+            errs = {k: rel(got[k], ref[k]) for k in ref}
+            if truth is not None:
+                print(f"   {prec} vs fp32 CPU oracle:", {k: f"{rel(got[k], truth[k]):.1e}" for k in ref})
+                print(f"   {prec} vs f32 mode      :", {k: f"{v:.1e}" for k, v in errs.items()})
+            worst = max(worst, max(errs.values()))
+            if max(errs.values()) > 2e-5:
+                k = max(errs, key=errs.get)
+                msgs.append(f"{prec}: {k} rel err {errs[k]:.2e}")
+            lg = ref["class_logits"].double().cpu()
+            top2 = lg.topk(2, dim=1).values
+            safe = (top2[:, 0] - top2[:, 1]) >= 2e-5 * float(lg.abs().max())
+            a0, a1 = ref["class_logits"].argmax(1).cpu(), got["class_logits"].argmax(1).cpu()
+            if not torch.equal(a0[safe], a1[safe]):
+                msgs.append(f"{prec}: argmax differs on {int((a0[safe] != a1[safe]).sum())} safe points")
+            if any(not torch.equal(got[k], again[k]) for k in got):
+                msgs.append(f"{prec}: not deterministic")
+            if any(not torch.isfinite(v).all() for v in got.values()):
+                msgs.append(f"{prec}: non-finite output")
+        print(f"case {case:3d}: C={C} {kind} B={B} N={N:4d} mhlnes={mh} ckpt={variant:8s} seed={seed:6d}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
+        bad += bool(msgs)
+        del net
+    print(f"{ncases} cases, {bad} with violations, worst relative difference to the exact-fp32 mode {worst:.2e}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
