@@ -34,6 +34,16 @@ def test_direct_invocation_launches_its_own_ranks():
     assert "roofline" not in d and "cpu_baseline" not in d                     # a stub line can never pass for a measurement
 
 
+def test_eight_ranks_as_the_driver_will_run_it():
+    """World size 8 (the driver's largest run) through the same plumbing: launcher, pipelined all-gather, max-over-ranks timing."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "4", "--warmup", "2", "--stub", "--batch", "2", "--points", "128"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["world_size_seen"] == 8 and d["config"]["global_batch"] == 16
+    assert d["gathered_rows"] == 16 and d["gathered_rank_ids"] == list(range(8))
+
+
 def test_in_order_gather_variant_of_the_step():
     """EV2H_BENCH_SYNC_GATHER=1: one gather buffer, the all-gather in stream order (the default alternates two buffers and issues it
     asynchronously); both variants must deliver every shard."""
