@@ -44,6 +44,22 @@ def test_eight_ranks_as_the_driver_will_run_it():
     assert d["gathered_rows"] == 16 and d["gathered_rank_ids"] == list(range(8))
 
 
+def test_under_torch_distributed_run_exactly_as_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`:
+    the ranks exist already, bench.py must run as a rank (no launcher of its own) and exactly one JSON line must come out."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub", "--batch", "2", "--points", "128"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _line(p.stdout)
+    assert d["n_gpus"] == 2 and d["gathered_rows"] == 4 and d["gathered_rank_ids"] == [0, 1]
+
+
 def test_in_order_gather_variant_of_the_step():
     """EV2H_BENCH_SYNC_GATHER=1: one gather buffer, the all-gather in stream order (the default alternates two buffers and issues it
     asynchronously); both variants must deliver every shard."""
