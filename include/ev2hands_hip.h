@@ -117,7 +117,7 @@ typedef struct ev2h_gemm_desc {
     int taps;                    /* 1, or 3 = Conv1d(k=3, padding=1) along rows, zero padded per sequence */
     int rows_per_seq;            /* rows per window when taps == 3                                      */
     int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
-    int precision;               /* EV2H_PREC_*; all but F32 need K % 8 == 0 (operands are split on the fly) */
+    int precision;               /* EV2H_PREC_*; all but F32 need K % 8 == 0 (operands are split on the fly), K % 16 == 0 with taps == 3 */
     const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in (ws_tile_rows)-row x 32-k LDS
                                     tiles (ev2hands_amd/pack.py: gemm_bf16_w_image); NULL = split W on the fly  */
     int ws_tile_rows;            /* 128 (three 4-wave workgroups per CU) or 256 (one 8-wave workgroup)           */
