@@ -1,8 +1,8 @@
 """Which summation order does this host's torch-CPU matmul use for the K=3 distance dot products?  (lattice cloud: every order
-mismatch is visible; compare with tests/diag on random data where it is not)"""
+mismatch is visible; compare with tests/diag_host_matmul.py on random data where it is not).  Imports oracle/: test tooling."""
 import os, sys, subprocess
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ev2hands_amd import synth
 from oracle import tehnet_oracle
 B, N, S = 2, 2048, 512

@@ -2,7 +2,7 @@
 reference's own ERPCParser.__getitem__: ragged batches of windows with 1 ... 32768 events, uniform / clustered / single-row / edge
 pixels, tied and huge timestamps, polarity values other than {0, 1}.  Bit-exact tables and normalised tensors (NaN positions
 included: a window whose pixels share one mean time normalises to 0/0 in the reference as well).
-usage: python tools/fuzz_events.py [nbatches] [seed]"""
+usage: python tests/fuzz_events.py [nbatches] [seed]"""
 import os
 import sys
 

@@ -6,7 +6,7 @@ activations) and FPS starts, runs the forward in exact fp32 and in f16x2 (and bf
   * every float output within 2e-5 relative of the exact-fp32 mode,
   * segmentation argmax identical wherever the fp32 top-2 margin exceeds 2e-5 of the logit scale,
   * a second run of the same case bit-identical (determinism).
-usage: python tools/fuzz_modes.py [ncases] [seed]          prints one line per case and a summary; exit code 1 on any violation."""
+usage: python tests/fuzz_modes.py [ncases] [seed]          prints one line per case and a summary; exit code 1 on any violation."""
 import os
 import sys
 

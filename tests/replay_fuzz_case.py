@@ -1,7 +1,7 @@
-"""Replay one fuzz case with diagnostics: python tools/debug/replay_fuzz_case.py C kind B N mhlnes seed [counts_x100] [variant]"""
+"""Replay one fuzz case with diagnostics (imports oracle/: test tooling): python tests/replay_fuzz_case.py C kind B N mhlnes seed [counts_x100] [variant]"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ev2hands_amd import synth
 from ev2hands_amd.model import TEHNetWrapper
 from fuzz_modes import run, rel, KEYS

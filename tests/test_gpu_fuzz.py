@@ -1,4 +1,4 @@
-"""GPU: randomised cross-check of the arithmetic modes (tools/fuzz_modes.py): random shapes, cloud kinds, MHLNES, checkpoints with
+"""GPU: randomised cross-check of the arithmetic modes (tests/fuzz_modes.py): random shapes, cloud kinds, MHLNES, checkpoints with
 per-channel rescaling / dead units / heavy tails / uniformly rescaled hidden activations; f16x2 (and bf16x3) against the exact-fp32
 mode of the same library: identical selections, <= 2e-5 relative on every output, argmax identical outside the 2e-5 rounding band,
 deterministic.  Round 3's first run of this found a precision leak no hand-written case had: a checkpoint with 1e6 x larger hidden
@@ -11,7 +11,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [11, 12])

@@ -305,3 +305,25 @@ def test_checkpoint_with_the_other_input_width_is_refused_clearly():
             net.load_state_dict({"module." + k: v for k, v in synth.synth_state_dict(ck_c, 1).items()}, strict=True)
         net.load_state_dict(synth.synth_state_dict(9 - ck_c, 1), strict=True)          # the matching width loads
     os.environ["ERPC"] = "0"
+
+
+def test_only_test_infrastructure_imports_the_oracle():
+    """oracle/ is the checker: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it -- never the product
+    package, and no tool either (fuzzers / diagnostics that need it live under tests/)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    offenders = []
+    for d, _, files in os.walk(root):
+        rel = os.path.relpath(d, root)
+        if rel.split(os.sep)[0] in ("tests", "oracle", ".git", "gpurun_out", "__pycache__", ".pytest_cache"):
+            continue
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(d, f), errors="replace").read()):
+                offenders.append(os.path.join(rel, f))
+    assert sorted(offenders) == ["./__graft_entry__.py", "./bench.py"], offenders
+    # ... and inside those two only where the contract allows it
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert bench.count("from oracle import") == 1 and bench.split("from oracle import")[0].rsplit("\ndef ", 1)[1].startswith("cpu_baseline(")
+    entry = open(os.path.join(root, "__graft_entry__.py")).read()
+    assert entry.count("from oracle import") == 1 and entry.split("from oracle import")[0].rsplit("\ndef ", 1)[1].startswith("smoke(")

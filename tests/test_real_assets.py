@@ -20,7 +20,8 @@ TOOL = os.path.join(ROOT, "tools", "validate_real_assets.py")
 def _make_dry_run(tmp_path):
     out = tmp_path / "dry.npz"
     assets = tmp_path / "assets"
-    r = subprocess.run([sys.executable, TOOL, "make", "--oracle", str(assets), "--out", str(out)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "real_assets_dryrun.py"), str(assets), str(out)], capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return str(out), str(assets)
 

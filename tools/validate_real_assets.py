@@ -22,8 +22,9 @@ Two steps, on two machines:
      recorded inputs through libev2hands_hip.so and reports max relative error per output, segmentation argmax agreement and the
      root-relative MPJPE (mm, evaluate_ev2hands_r.py:43-54) against the reference -- in every arithmetic mode.
 
-`make --oracle` replaces the reference by this repository's CPU oracle and a synthetic checkpoint / MANO-shaped assets written in
-the real file formats: a dry run of the whole procedure (tests/test_real_assets.py uses it).
+`python tests/real_assets_dryrun.py DIR OUT` replaces the reference by this repository's CPU oracle and a synthetic checkpoint /
+MANO-shaped assets written in the real file formats: a dry run of the whole procedure (tests/test_real_assets.py uses it; the oracle
+is test infrastructure, so that part lives under tests/).
 """
 from __future__ import annotations
 
@@ -97,53 +98,11 @@ def run_reference(ref_dir: str, mano_dir: str, sd: dict, C: int):
     return run
 
 
-def run_oracle(assets: dict, sd: dict):
-    from oracle import mano_oracle, tehnet_oracle
-    hands = mano_oracle.make_hands(assets["left"], assets["right"])
-
-    def run(xyz):
-        B, _, N = xyz.shape
-        drawn = [torch.randint(0, hi, (B,), dtype=torch.long) for hi in (N, synth.SA1_NPOINT, N, N)]
-        with torch.no_grad():
-            out = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=drawn)
-        return out, drawn
-    return run
-
-
-def write_synthetic_assets(out_dir: str, C: int = 5, seed: int = 7):
-    """A synthetic checkpoint and MANO-shaped pkl files in the REAL file formats (dry run of the procedure)."""
-    import scipy.sparse as sp
-    os.makedirs(os.path.join(out_dir, "mano"), exist_ok=True)
-    sd = synth.synth_state_dict(C, seed)
-    ckpt = os.path.join(out_dir, "best_model_state_dict.pth")
-    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}}, ckpt)
-    assets = {}
-    for side in ("left", "right"):
-        a = synth.synth_mano_assets(side, seed)
-        assets[side] = a
-        d = {"v_template": a["v_template"], "shapedirs": a["shapedirs"], "posedirs": a["posedirs"],
-             "J_regressor": sp.csc_matrix(a["J_regressor"]), "weights": a["weights"], "hands_components": a["hands_components"],
-             "hands_mean": a["hands_mean"], "f": a["faces"].astype(np.uint32),
-             "kintree_table": np.array([[4294967295] + a["parents"][1:], list(range(16))], dtype=np.int64)}
-        with open(os.path.join(out_dir, "mano", f"MANO_{side.upper()}.pkl"), "wb") as f:
-            pickle.dump(d, f, protocol=2)
-    return ckpt, out_dir, assets
-
-
-def cmd_make(a) -> int:
+def make_fixture(run, C: int, ckpt: str, mano_dir: str, out_path: str, source: str) -> int:
+    """Record `run(xyz) -> (outputs, [4 FPS start vectors])` on the seeded cases.  `run` is the reference's own wrapper (cmd_make);
+    the test suite's dry run passes the CPU oracle instead (tests/real_assets_dryrun.py -- the oracle is test infrastructure and is
+    not imported by this tool)."""
     torch.manual_seed(1234)
-    if a.oracle:
-        ckpt, mano_dir, assets = write_synthetic_assets(a.oracle)
-        sd = load_checkpoint(ckpt)
-        C = channels_of(sd)
-        run = run_oracle(assets, sd)
-        source = "oracle (dry run, synthetic assets)"
-    else:
-        ckpt, mano_dir = a.ckpt, a.mano
-        sd = load_checkpoint(ckpt)
-        C = channels_of(sd)
-        run = run_reference(a.reference, mano_dir, sd, C)
-        source = "reference"
     out = {"channels": np.array(C), "ncases": np.array(len(CASES)), "source": np.array(source),
            "sha256.ckpt": np.array(sha256(ckpt))}
     for side in ("left", "right"):
@@ -159,9 +118,15 @@ def cmd_make(a) -> int:
                 out[f"{i}.{side}.{k}"] = res[side][k].detach().numpy()
         print(f"case {i}: {kind}-cloud B={B} N={N}: logits scale {float(res['class_logits'].abs().max()):.3g}, "
               f"class histogram {torch.bincount(res['class_logits'].argmax(1).flatten(), minlength=4).tolist()}")
-    np.savez_compressed(a.out, **out)
-    print(f"wrote {a.out} ({os.path.getsize(a.out) // 1024} KiB) from the {source}")
+    np.savez_compressed(out_path, **out)
+    print(f"wrote {out_path} ({os.path.getsize(out_path) // 1024} KiB) from the {source}")
     return 0
+
+
+def cmd_make(a) -> int:
+    sd = load_checkpoint(a.ckpt)
+    C = channels_of(sd)
+    return make_fixture(run_reference(a.reference, a.mano, sd, C), C, a.ckpt, a.mano, a.out, "reference")
 
 
 # ------------------------------------------------------------------------------------------------ check
@@ -231,7 +196,6 @@ def main() -> int:
     m.add_argument("--reference", help="path to Ev2Hands/src/Ev2Hands of the reference checkout")
     m.add_argument("--mano", help="directory that holds mano/MANO_{LEFT,RIGHT}.pkl (settings.MANO_PATH)")
     m.add_argument("--ckpt", help="best_model_state_dict.pth")
-    m.add_argument("--oracle", metavar="DIR", help="dry run: write synthetic assets in the real formats into DIR and use the CPU oracle")
     m.add_argument("--out", required=True)
     c = sub.add_parser("check")
     c.add_argument("--fixture", required=True)
@@ -239,8 +203,8 @@ def main() -> int:
     c.add_argument("--ckpt", required=True)
     a = ap.parse_args()
     if a.cmd == "make":
-        if not a.oracle and not (a.reference and a.mano and a.ckpt):
-            ap.error("make needs --reference, --mano and --ckpt (or --oracle DIR for a dry run)")
+        if not (a.reference and a.mano and a.ckpt):
+            ap.error("make needs --reference, --mano and --ckpt (a dry run with synthetic assets: python tests/real_assets_dryrun.py DIR OUT)")
         return cmd_make(a)
     return cmd_check(a)
 
