@@ -75,6 +75,11 @@ def parse(argv=None):
     ap.add_argument("--collision", action="store_true",
                     help="BASELINE config 5: add the two-hand self-collision term to every step (pair search with the evaluation's "
                          "max_collisions = 8, then the intersection loss's pair search with 16 and its distance-field penalty)")
+    ap.add_argument("--collision-mesh", default="surface", choices=["surface", "soup"],
+                    help="geometry of the synthetic hand assets for --collision: 'surface' = a mitten-shaped mesh with smooth blend shapes and "
+                         "skinning (deforms like a hand mesh: tens to hundreds of colliding triangle pairs per window), 'soup' = the default "
+                         "parity assets, whose vertices and faces are independent random draws (every mesh intersects itself ~24 000 times: "
+                         "the worst case for the pair search)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--stub", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (launcher, gloo all-gather, max-over-ranks timing) with fabricated "
@@ -387,7 +392,10 @@ def run_rank(a) -> int:
         from ev2hands_amd.model import TEHNetWrapper
         os.environ["ERPC"] = "1" if Cc == 5 else "0"
         os.environ["EV2H_PRECISION"] = a.precision
-        assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
+        if a.collision and a.collision_mesh == "surface":
+            assets = {s: synth.synth_mano_surface_assets(s, 0) for s in ("left", "right")}
+        else:
+            assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
         sd = synth.synth_state_dict(Cc, 0)
         net = TEHNetWrapper(dev, mano_assets=assets)
         net.load_state_dict(sd, strict=True)
@@ -501,8 +509,10 @@ def run_rank(a) -> int:
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
                                    f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
                                    + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16, pair list sized 2 x 1538 x 16 per window: never "
-                                      "truncated) per window (the synthetic hand meshes are random geometry and intersect themselves ~24 000 times: worst case "
-                                      "for the pair search)" if a.collision else ""),
+                                      "truncated) per window; hand meshes: " +
+                                      ("mitten-shaped surfaces with smooth skinning (tens to hundreds of colliding pairs per window)" if a.collision_mesh == "surface"
+                                       else "random triangle soup (every mesh intersects itself ~24 000 times: worst case for the pair search)")
+                                      if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
                        "parallelism": f"batch-shard x{world}" + ((" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer; " +

@@ -302,6 +302,66 @@ def synth_mano_assets(side: str, seed: int = 0) -> dict:
     }
 
 
+def synth_mano_surface_assets(side: str, seed: int = 0) -> dict:
+    """A MANO-shaped asset whose template IS a surface: a mitten (half ellipsoid, open at the wrist like MANO's mesh) of 37 rings x 21
+    segments + a tip vertex = 778 vertices, 1512 + 21 triangles + 5 repeated ones = 1538 faces, smooth low-frequency blend
+    shapes, 16 joints inside the volume with a J_regressor of local vertex averages and smooth (distance-based, 3 joints per
+    vertex) skinning weights.  synth_mano_assets() above draws vertices and faces independently -- triangle soup in which every
+    mesh intersects itself ~24 000 times, the worst case for the collision search; this one deforms like a hand mesh does (few
+    or no self-intersections), which is what the two-hand collision term of BASELINE config 5 meets in practice.  Same array
+    shapes and keys; used by `bench.py --collision` (both geometries are reported), not by the parity fixtures."""
+    tag = f"mano_surface/{side}"
+    s = 1.0 if side == "right" else -1.0
+    R, S = 37, 21
+    t = (np.arange(R) / R)[:, None]                                   # 0 (wrist) .. 0.973
+    phi = (2 * np.pi * np.arange(S) / S)[None, :]
+    prof = np.sqrt(1.0 - 0.95 * t ** 2)
+    vx, vy, vz = 0.040 * prof * np.cos(phi), 0.09 * t + 0 * phi, 0.012 * prof * np.sin(phi)
+    v = np.concatenate([np.stack([vx, vy, vz], -1).reshape(-1, 3), np.array([[0.0, 0.0915, 0.0]])], 0)      # 777 + tip
+    assert v.shape[0] == MANO_NV
+    faces = []
+    for i in range(R - 1):
+        for j in range(S):
+            a, b, c, d = i * S + j, i * S + (j + 1) % S, (i + 1) * S + (j + 1) % S, (i + 1) * S + j
+            faces += [(a, b, c), (a, c, d)]
+    tip = R * S
+    faces += [((R - 1) * S + j, (R - 1) * S + (j + 1) % S, tip) for j in range(S)]
+    faces += faces[:MANO_NF - len(faces)]                             # 5 repeats (share all vertices with their originals: never a pair)
+    faces = np.asarray(faces, dtype=np.int64)
+    assert faces.shape == (MANO_NF, 3)
+    # smooth fields over the surface: a few low-frequency modes of (t, phi) per direction
+    tt = np.concatenate([np.repeat(t[:, 0], S), [1.0]])
+    pp = np.concatenate([np.tile(phi[0], R), [0.0]])
+
+    def smooth(name, k, amp):
+        c = hash_normal(tag + "/" + name, (k, 3, 4), seed)
+        ph = hash_uniform(tag + "/" + name + "/ph", (k, 3, 4), seed) * 2 * np.pi
+        basis = np.stack([np.sin(np.pi * tt), np.sin(2 * np.pi * tt), np.cos(pp) * np.sin(np.pi * tt), np.sin(pp) * np.sin(np.pi * tt)], 0)   # [4, V]
+        f = np.einsum("kcm,kcmv->vck", c, np.cos(ph)[..., None] * basis[None, None])
+        return amp * f / 2.0
+    shapedirs = smooth("sd", 10, 1.0e-3)
+    posedirs = smooth("pd", 135, 2.0e-4)
+    # joints: the root at the wrist, five chains of three along the mitten
+    targets = [np.array([0.0, 0.005, 0.0])]
+    for f_, x0 in enumerate(np.linspace(-0.026, 0.026, 5)):
+        for y0 in (0.030, 0.052, 0.072):
+            targets.append(np.array([x0 * (1.0 - 0.5 * (y0 / 0.09) ** 2), y0, 0.0]))
+    targets = np.stack(targets)                                       # [16, 3] in MANO's joint order (root, 5 x 3)
+    d2 = ((v[None] - targets[:, None]) ** 2).sum(-1)                   # [16, V]
+    jr = np.exp(-d2 / 0.012 ** 2) + 1e-12
+    jr /= jr.sum(1, keepdims=True)
+    J = jr @ v
+    w = np.exp(-(((v[:, None] - J[None]) ** 2).sum(-1)) / 0.018 ** 2) + 1e-12
+    thresh = np.sort(w, axis=1)[:, -3][:, None]
+    w = np.where(w >= thresh, w, 0.0)
+    w /= w.sum(1, keepdims=True)
+    v = v.copy()
+    v[:, 0] = v[:, 0] * s + 0.09 * s
+    base = synth_mano_assets(side, seed)
+    return {"side": side, "v_template": v, "shapedirs": shapedirs, "posedirs": posedirs, "J_regressor": jr, "weights": w,
+            "hands_components": base["hands_components"], "hands_mean": base["hands_mean"], "faces": faces, "parents": list(MANO_PARENTS)}
+
+
 def rescale_hidden(sd: dict, alpha: float) -> "OrderedDict":
     """Checkpoint whose hidden activations are `alpha` times those of `sd` while the network function is unchanged
     (ReLU is positively homogeneous): every eval-BatchNorm's weight and bias are multiplied by alpha, and the columns of the next

@@ -327,3 +327,33 @@ def test_only_test_infrastructure_imports_the_oracle():
     assert bench.count("from oracle import") == 1 and bench.split("from oracle import")[0].rsplit("\ndef ", 1)[1].startswith("cpu_baseline(")
     entry = open(os.path.join(root, "__graft_entry__.py")).read()
     assert entry.count("from oracle import") == 1 and entry.split("from oracle import")[0].rsplit("\ndef ", 1)[1].startswith("smoke(")
+
+
+def test_surface_like_synthetic_hand_assets():
+    """synth_mano_surface_assets: same shapes / invariants as the parity assets (rows of J_regressor and of the skinning weights
+    non-negative and summing to 1, 3 joints per vertex), but the template is a surface: neighbouring faces share edges, and a posed
+    pair of hands collides in tens of triangle pairs, not tens of thousands (checked with the collision oracle)."""
+    from oracle import collision_oracle as CO, mano_oracle
+    a = {s: synth.synth_mano_surface_assets(s, 0) for s in ("left", "right")}
+    b = synth.synth_mano_assets("left", 0)
+    for k, v in b.items():
+        if hasattr(v, "shape"):
+            assert a["left"][k].shape == v.shape, k
+    for s in ("left", "right"):
+        jr, w = a[s]["J_regressor"], a[s]["weights"]
+        assert (jr >= 0).all() and np.allclose(jr.sum(1), 1) and (w >= 0).all() and np.allclose(w.sum(1), 1) and ((w > 0).sum(1) <= 3).all()
+        f = a[s]["faces"]
+        assert f.min() == 0 and f.max() == 777
+        edges = np.sort(np.concatenate([f[:1533, [0, 1]], f[:1533, [1, 2]], f[:1533, [2, 0]]]), 1)
+        _, cnt = np.unique(edges, axis=0, return_counts=True)
+        assert (cnt <= 2).all() and (cnt == 2).mean() > 0.98          # a manifold with one open rim (the wrist)
+    hands = mano_oracle.make_hands(a["left"], a["right"])
+    g = torch.Generator().manual_seed(0)
+    v = {}
+    for s in ("left", "right"):
+        o = hands[s](global_orient=torch.randn(2, 3, generator=g) * 0.2, hand_pose=torch.randn(2, 6, generator=g) * 0.3,
+                     betas=torch.randn(2, 10, generator=g) * 0.3, transl=torch.randn(2, 3, generator=g) * 0.05)
+        v[s] = o.vertices.numpy()
+    for i in range(2):
+        vv, ff = CO.build_triangles(v["left"][i], v["right"][i], a["left"]["faces"], a["right"]["faces"], scale=1000.0)
+        assert CO.collision_pairs(vv, ff, 8).shape[0] < 1000
