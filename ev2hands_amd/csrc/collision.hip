@@ -74,6 +74,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     int* srow = reinterpret_cast<int*>(sbb + 6 * F2);           // [F2 + 1] pairs per row, then exclusive prefix
     int* spart = srow + F2 + 1;                                 // [COL_THREADS] scan scratch
     int* squeue = spart + COL_THREADS + (threadIdx.x >> 6) * 128;   // [waves][128] this wave's candidates: (lane << 16) | column
+    float* sblk = reinterpret_cast<float*>(spart + COL_THREADS + (COL_THREADS >> 6) * 128);   // [nblk][6] box of every 64-triangle block
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < 3 * V2; i += COL_THREADS) {
@@ -96,6 +97,27 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { sbb[6 * f + c] = lo[c]; sbb[6 * f + 3 + c] = hi[c]; }
+    }
+    __syncthreads();
+
+    // Two-level culling: the bounding box of every block of 64 consecutive triangles.  A (row block, column block) pair whose
+    // boxes are disjoint cannot hold an overlapping triangle pair and is skipped as a whole -- conservative, so the candidates,
+    // their order and therefore the counts, caps and pair lists are exactly those of the full walk.  Mesh faces are stored
+    // locally coherent (a block is a patch of the surface), and the two hands are usually apart: a hand-like pair of meshes
+    // keeps ~1/8 of the block pairs (profiles/r3_collision_timing.txt); random triangle soup keeps all of them.
+    {
+        const int nblk_ = (F2 + 63) >> 6;
+        for (int kb = wave; kb < nblk_; kb += (COL_THREADS >> 6)) {
+            const int f = kb * 64 + lane;
+            float v[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { v[c] = f < F2 ? sbb[6 * f + c] : INFINITY; v[3 + c] = f < F2 ? sbb[6 * f + 3 + c] : -INFINITY; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { v[c] = fminf(v[c], __shfl_xor(v[c], o, 64)); v[3 + c] = fmaxf(v[3 + c], __shfl_xor(v[3 + c], o, 64)); }
+            if (lane < 6) sblk[6 * kb + lane] = v[lane];
+        }
     }
     __syncthreads();
 
@@ -143,7 +165,12 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
                 if (lane < rest) squeue[lane] = keep;
                 qn = rest;
             };
-            for (int j = rb * 64 + 1; j < F2; ++j) {            // wave-uniform column: LDS broadcasts
+            const float* rbx = sblk + 6 * rb;
+            for (int jb = rb; jb < nblk; ++jb) {                // column blocks in order; disjoint block boxes are skipped whole
+                const float* cbx = sblk + 6 * jb;
+                if (!(rbx[0] <= cbx[3] && cbx[0] <= rbx[3] && rbx[1] <= cbx[4] && cbx[1] <= rbx[4] && rbx[2] <= cbx[5] && cbx[2] <= rbx[5])) continue;
+            const int j_end = min(F2, jb * 64 + 64);
+            for (int j = max(jb * 64, rb * 64 + 1); j < j_end; ++j) {            // wave-uniform column: LDS broadcasts
                 const float* bj = sbb + 6 * j;
                 bool ov = valid && j > i && (p.cap <= 0 || cnt < p.cap) && lo[0] <= bj[3] && bj[0] <= hi[0] && lo[1] <= bj[4] &&
                           bj[1] <= hi[1] && lo[2] <= bj[5] && bj[2] <= hi[2];
@@ -161,6 +188,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
                     qn += __popcll(m);
                     if (qn >= 64) drain(64);
                 }
+            }
             }
             while (qn > 0) drain(min(qn, 64));
             if (!pass && valid) srow[i] = cnt;
@@ -279,7 +307,7 @@ extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_
     EV2H_CHECK_ARG(max_per_triangle >= 0);
     ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts, max_per_triangle};
     const size_t lds = (size_t)(3 * 2 * nv) * 4 + (size_t)(3 * 2 * nf) * 4 + (size_t)(6 * 2 * nf) * 4 + (size_t)(2 * nf + 1) * 4 +
-                       COL_THREADS * 4 + (COL_THREADS / 64) * 128 * 4;
+                       COL_THREADS * 4 + (COL_THREADS / 64) * 128 * 4 + (size_t)((2 * nf + 63) / 64) * 6 * 4;
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
