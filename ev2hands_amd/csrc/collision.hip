@@ -127,6 +127,12 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     };
     const int nblk = (F2 + 63) >> 6, nwaves = COL_THREADS >> 6;
     int32_t* out = p.pairs ? p.pairs + (size_t)b * p.max_pairs * 2 : nullptr;
+    // ONE walk when every row's pairs fit a fixed slot range of the output (a per-triangle cap and a list of >= F2 * cap entries, the
+    // default capacity of ev2hands_amd.collision.CollisionLoss): row i writes its accepted pairs at slots [i * cap, i * cap + cnt_i)
+    // during the counting walk, and the list is compacted in place afterwards (destinations never lie behind their sources, rows
+    // ascending: a chunk is read into registers, then written).  Same acceptance order, hence the same list as the two-walk form,
+    // for half the separating-axis tests.
+    const bool one_walk = out && p.cap > 0 && (long)p.max_pairs >= (long)F2 * p.cap;
 
     for (int pass = 0; pass < 2; ++pass) {
         for (int rb = wave; rb < nblk; rb += nwaves) {
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) { lo[c] = sbb[6 * ii + c]; hi[c] = sbb[6 * ii + 3 + c]; fi[c] = sf[3 * ii + c]; }
             int cnt = 0;
-            const int base = pass ? srow[ii] : 0;
+            const int base = one_walk ? ii * p.cap : (pass ? srow[ii] : 0);
             int qn = 0;                                         // queued candidates (wave-uniform)
             // the first n queued candidates: one float64 test per lane, then every row's owner applies its verdicts in queue order
             auto drain = [&](int n) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
                 for (int k = 0; k < n; ++k) {
                     const int e = squeue[k];                    // LDS broadcast
                     if (((hm >> k) & 1ull) && (e >> 16) == lane && (p.cap <= 0 || cnt < p.cap)) {   // at most `cap` pairs per triangle i, in j order
-                        if (pass && out && base + cnt < p.max_pairs) { out[2 * (base + cnt)] = i; out[2 * (base + cnt) + 1] = e & 0xffff; }
+                        if ((pass || one_walk) && out && base + cnt < p.max_pairs) { out[2 * (base + cnt)] = i; out[2 * (base + cnt) + 1] = e & 0xffff; }
                         ++cnt;
                     }
                 }
@@ -210,9 +216,26 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
         }
         int run = spart[tid] - s;
         for (int r = lo_r; r < hi_r; ++r) { const int c = srow[r]; srow[r] = run; run += c; }
-        if (tid == COL_THREADS - 1) p.counts[b] = spart[tid];
+        if (tid == COL_THREADS - 1) { p.counts[b] = spart[tid]; srow[F2] = spart[tid]; }
         if (!out) break;                                        // counts only: the second walk would repeat every test for nothing
         __syncthreads();
+        if (one_walk) {
+            // in-place compaction of the per-row slot ranges: entry e = (row r = e / cap, k = e % cap) is live iff k < cnt_r and moves
+            // to srow[r] + k <= e
+            const int total_slots = F2 * p.cap;
+            for (int e0 = 0; e0 < total_slots; e0 += COL_THREADS) {
+                const int e = e0 + tid;
+                int a = 0, c = 0, dst = -1;
+                if (e < total_slots) {
+                    const int r = e / p.cap, k = e - r * p.cap;
+                    if (k < srow[r + 1] - srow[r]) { dst = srow[r] + k; a = out[2 * e]; c = out[2 * e + 1]; }
+                }
+                __syncthreads();
+                if (dst >= 0 && dst != e) { out[2 * dst] = a; out[2 * dst + 1] = c; }
+                __syncthreads();
+            }
+            break;
+        }
     }
 }
 

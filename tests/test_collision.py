@@ -203,3 +203,34 @@ def test_gpu_collision_loss_capacity_and_quirk():
     q = CollisionLoss("cuda:0", reference_batch_quirk=True)
     wantq, _ = CO.collision_loss(vl, vr, f, f, reference_batch_quirk=True)
     assert float(q(outs)) == pytest.approx(wantq, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap", [1, 3, 16])
+def test_gpu_capped_pair_list_one_walk_equals_two_walks_and_the_oracle(cap):
+    """With a per-triangle cap and a list of >= n_triangles * cap entries the kernel writes each row's pairs into a slot range
+    during the counting walk and compacts in place (one walk); with a smaller list it counts, prefix-sums and walks again.  Both
+    must give the oracle's capped list, entry for entry, also when the cap is active on many rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ev2hands_amd.collision import mesh_collisions
+    v, f = CO.icosphere(3)
+    B = 4
+    rng = np.random.default_rng(3)
+    vl = np.stack([(v * 0.040 * (1 + 0.05 * rng.normal(size=(1, 3)))).astype(np.float32) for _ in range(B)])
+    off = np.array([[0.2, 0, 0], [0.05, 0.003, 0.001], [0.01, 0.0, 0.0], [0.0, 0.0005, 0.0]])
+    vr = np.stack([(v * 0.040 + off[b]).astype(np.float32) for b in range(B)])
+    tl, tr = torch.from_numpy(vl).cuda(), torch.from_numpy(vr).cuda()
+    F2 = 2 * f.shape[0]
+    c1, p1 = mesh_collisions(tl, tr, f, f, max_pairs=F2 * cap, scale=1.0, max_per_triangle=cap)            # one walk
+    c2, p2 = mesh_collisions(tl, tr, f, f, max_pairs=F2 * cap - 1, scale=1.0, max_per_triangle=cap)        # two walks
+    assert torch.equal(c1, c2)
+    for b in range(B):
+        vv, ff = CO.build_triangles(vl[b], vr[b], f, f, scale=1.0)
+        ref = CO.collision_pairs(vv, ff, cap)
+        n = int(c1[b])
+        assert n == ref.shape[0]
+        assert np.array_equal(p1[b, :n].cpu().numpy(), ref)
+        m = min(n, F2 * cap - 1)
+        assert np.array_equal(p2[b, :m].cpu().numpy(), ref[:m])
+    assert int(c1[0]) == 0 and int(c1[2]) > 50
