@@ -66,7 +66,17 @@ class Weights(C.Structure):
                 ("cls0", Dense), ("cls4", Dense), ("clsm", SaBranch),
                 ("qconv0", Dense), ("qconv4", Dense * 2), ("qconv4T", vp * 2),
                 ("mano_sa2", (Dense * 2) * 2),
-                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci), ("l0_unscale", vp)]
+                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci), ("l0_unscale", vp), ("flags", ci)]
+
+
+class TensorDesc(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("dtype", ci), ("ndim", ci), ("shape", C.c_int64 * 4)]
+
+
+DT_F32, DT_F64, DT_I64 = 0, 1, 2
+PACK_EQUALIZE, PACK_HOST_ONLY, PACK_UNEQUALIZED_OK = 1, 2, 4
+W_EQUALIZED, W_UNEQUALIZED_OK = 1, 2
+ABI_VERSION = 6     # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs; 6: ev2h_pack_weights, ev2h_weights.flags
 
 PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
 
@@ -88,6 +98,9 @@ EXPORTS = [
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
     "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
+    "ev2h_pack_weights", "ev2h_packed_free", "ev2h_packed_weights", "ev2h_packed_bytes", "ev2h_packed_tensor_count", "ev2h_packed_tensor",
+    "ev2h_packed_equalization_count", "ev2h_packed_equalization", "ev2h_pack_sa_image_bytes", "ev2h_pack_sa_images",
+    "ev2h_pack_gemm_image_bytes", "ev2h_pack_gemm_image", "ev2h_plane_unscale",
     "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
 ]
 
@@ -116,7 +129,7 @@ def lib() -> C.CDLL:
     L.ev2h_workspace_buffer.restype = vp
     L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
     L.ev2h_struct_sizes.restype = None
-    L.ev2h_struct_sizes.argtypes = [C.c_size_t * 7]
+    L.ev2h_struct_sizes.argtypes = [C.c_size_t * 8]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -143,13 +156,31 @@ def lib() -> C.CDLL:
     L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp]
     L.ev2h_collision_penalty.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, C.c_double, vp, vp, ci, vp, vp]
     L.ev2h_profile_set.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), ci]
-    sizes = (C.c_size_t * 7)()
+    L.ev2h_pack_weights.argtypes = [C.POINTER(TensorDesc), ci, ci, ci, ci, C.POINTER(vp)]
+    L.ev2h_packed_free.restype = None
+    L.ev2h_packed_free.argtypes = [vp]
+    L.ev2h_packed_weights.restype = vp
+    L.ev2h_packed_weights.argtypes = [vp]
+    L.ev2h_packed_bytes.restype = C.c_size_t
+    L.ev2h_packed_bytes.argtypes = [vp]
+    L.ev2h_packed_tensor_count.argtypes = [vp]
+    L.ev2h_packed_tensor.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]
+    L.ev2h_packed_equalization_count.argtypes = [vp]
+    L.ev2h_packed_equalization.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(ci)]
+    L.ev2h_pack_sa_image_bytes.argtypes = [ci, ci, ci, ci, C.c_size_t * 2]
+    L.ev2h_pack_sa_images.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ev2h_pack_gemm_image_bytes.restype = C.c_size_t
+    L.ev2h_pack_gemm_image_bytes.argtypes = [ci, ci, ci, ci]
+    L.ev2h_pack_gemm_image.argtypes = [vp, ci, ci, ci, ci, vp, C.POINTER(C.c_float)]
+    L.ev2h_plane_unscale.restype = C.c_float
+    L.ev2h_plane_unscale.argtypes = [vp, C.c_size_t, ci]
+    sizes = (C.c_size_t * 8)()
     L.ev2h_struct_sizes(sizes)
-    mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs, FpDesc)]
+    mine = [C.sizeof(t) for t in (GemmDesc, SaDesc, SaModule, Weights, ManoConsts, Outputs, FpDesc, TensorDesc)]
     if list(sizes) != mine:
         raise Ev2hError(f"struct layout mismatch between ev2hands_hip.h and _lib.py: {list(sizes)} vs {mine}")
-    if L.ev2h_abi_version() != 5:      # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs
-        raise Ev2hError("ABI version mismatch")
+    if L.ev2h_abi_version() != ABI_VERSION:
+        raise Ev2hError(f"ABI version mismatch: library {L.ev2h_abi_version()}, binding {ABI_VERSION}")
     _lib = L
     return L
 

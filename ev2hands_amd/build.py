@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 OUT = os.path.join(HERE, "libev2hands_hip.so")
-SOURCES = ["points.hip", "gemm.hip", "gemm_bf16.hip", "sa_mlp.hip", "sa_mlp_bf16.hip", "attention.hip", "mano.hip", "events.hip", "metrics.hip", "collision.hip", "forward.hip"]
+SOURCES = ["points.hip", "gemm.hip", "gemm_bf16.hip", "sa_mlp.hip", "sa_mlp_bf16.hip", "attention.hip", "mano.hip", "events.hip", "metrics.hip", "collision.hip", "pack.hip", "forward.hip"]
 
 
 def needs_build() -> bool:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 5
+#define EV2H_ABI_VERSION 6
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -36,8 +36,19 @@ typedef void* ev2h_stream_t; /* hipStream_t */
  *  BF16X3  each fp32 operand split exactly into 3 bf16 planes, 6 plane products on
  *          v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32-class accuracy (dropped terms O(2^-24));
  *  F16X2   each fp32 operand split into 2 fp16 planes (11 + 11 mantissa bits), 3 plane products on
- *          v_mfma_f32_32x32x16_f16 with fp32 accumulation: dropped terms O(2^-22), operands must stay below 65504
- *          in magnitude (weights are checked at pack time), absolute error <= 2^-25 for tiny operands;
+ *          v_mfma_f32_32x32x16_f16 with fp32 accumulation: dropped terms O(2^-22).  ACCURACY CONTRACT (fp16 has 5 exponent bits):
+ *          every operand tensor is scaled by ONE exact power of two per event window (activations, "Range records" below) or per
+ *          matrix (weights, w_unscale), so its maximum sits in [2^14, 2^15) and nothing can overflow; a value keeps its full
+ *          22 bits only down to 2^-17 of that maximum and an absolute error <= 2^-39 of the maximum below.  The mode is
+ *          therefore fp32-class (<= 1e-5 relative on every output) only if no operand that matters lies more than 2^17 below
+ *          its window's / matrix's maximum.  A checkpoint may distribute magnitude between a hidden channel and the weights
+ *          that read it arbitrarily (BatchNorm scales): ev2h_pack_weights removes that freedom with an exact power-of-two
+ *          per-channel equalisation (EV2H_PACK_EQUALIZE).  Measured WITHOUT it on otherwise identical networks: 6.6e-4 relative
+ *          error with hidden channels 2^16 apart, 0.23 with channels 2^24 apart; with it <= 1.3e-6 up to 2^32 apart
+ *          (tests/test_gpu_range.py, profiles/r3_spread_report.txt).  ev2h_forward refuses F16X2 weights that are not marked
+ *          EV2H_W_EQUALIZED unless the caller opts out with EV2H_W_UNEQUALIZED_OK.  What no packer can see is a spread BETWEEN
+ *          POINTS or between channels that only the data produces: ev2h_range_report counts, per tensor and window, the values
+ *          that sit below 2^-17 of the maximum, and BF16X3 / F32 have no such limit;
  *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3).
  * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the K = 8
  * layer-1 tables of the raw cloud, the one-row-per-window layers (ev2h_gemm_desc.skinny) and the folded attention product
@@ -65,8 +76,8 @@ const char* ev2h_last_error(void);
  * two-stream overlaps (~5 % of a B = 256 step).  (Raising GPU_MAX_HW_QUEUES is no substitute: 8 queues cured the late-creation case
  * but cost 10 % when the side stream was created first.) */
 int ev2h_init(void);
-/* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp]. */
-void ev2h_struct_sizes(size_t out[7]);
+/* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp, tensor_desc]. */
+void ev2h_struct_sizes(size_t out[8]);
 
 /* ---- point-set operators --------------------------------------------------------------------- */
 /* [B,C,N] channel-major input -> pts4 [B][N][4] = (x, y, z, (x*x+y*y)+z*z) and feat8 [B][N][8]
@@ -119,11 +130,11 @@ typedef struct ev2h_gemm_desc {
     int rowmax_rows;             /* 0, or 128: write max over each 128-row group (group-all set abstraction) */
     int precision;               /* EV2H_PREC_*; all but F32 need K % 8 == 0 (operands are split on the fly), K % 16 == 0 with taps == 3 */
     const void* Ws;              /* optional, BF16 / BF16X3: bf16 plane images of W in (ws_tile_rows)-row x 32-k LDS
-                                    tiles (ev2hands_amd/pack.py: gemm_bf16_w_image); NULL = split W on the fly  */
+                                    tiles (ev2h_pack_gemm_image); NULL = split W on the fly  */
     int ws_tile_rows;            /* 128 (three 4-wave workgroups per CU) or 256 (one 8-wave workgroup)           */
     float w_unscale;             /* 16-bit precisions: W is used as W / w_unscale (Ws holds those planes) and the product is
                                     multiplied by w_unscale before the bias; a power of two chosen by the host so that the
-                                    fp16 planes of small weights are not subnormal (pack.py: plane_unscale).  0 = 1.      */
+                                    fp16 planes of small weights are not subnormal (ev2h_plane_unscale).  0 = 1.      */
     /* F16X2 activation range (ignored by the other precisions; see "Range records" below).  All optional. */
     const uint32_t* x_amax;      /* [ceil(M / x_group_rows)] range record of X: rows of group g are multiplied by the power of   */
     const uint32_t* x_amax2;     /* two that puts max(x_amax[g], x_amax2[g]) in [2^14, 2^15) before the fp16 split (x_amax2:     */
@@ -165,7 +176,7 @@ typedef struct ev2h_sa_desc {
     int B, Npts, S, K;           /* K multiple of 32                                                    */
     int C1, C2, C3;
     int precision;               /* EV2H_PREC_*                                                         */
-    const void* W2s;             /* bf16 tile images of W2 / W3 for BF16 / BF16X3 (ev2hands_amd/pack.py), */
+    const void* W2s;             /* bf16 tile images of W2 / W3 for the 16-bit modes (ev2h_pack_sa_images), */
     const void* W3s;             /* NULL for F32                                                        */
     const int32_t* cnt;          /* optional: cnt[(b*S + s) * cnt_ld] = number of distinct neighbours of the group   */
     float w2_unscale, w3_unscale;/* power-of-two factors the W2s / W3s planes were divided by (0 = 1), see ev2h_gemm_desc   */
@@ -232,8 +243,8 @@ int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
  * LEFTOVER (0, or the 1..4 channels beyond the last full 32-channel tile whose plane products share MFMAs: the images then carry,
  * in the HIGH plane, the low plane of the leftover W2 rows in rows 8..11 of the last tile and [wh | wh | wl | 0] in the last 16
  * k-slots of every W3 row -- csrc/sa_mlp_bf16.hip SaBCfg::PACK4), 0 }.
- * A host packer asserts its own layout against this (ev2hands_amd/pack.py does at load time), so the kernels and the packer
- * cannot drift apart silently.  Needs no GPU. */
+ * The library's own packer (ev2h_pack_weights, ev2h_pack_sa_images) asserts its layout against this on every pack, so the kernels
+ * and the packer cannot drift apart silently; a caller that builds images itself can do the same.  Needs no GPU. */
 int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10]);
 
 /* ---- attention (model/TEHNet.py:13-27) ------------------------------------------------------------ */
@@ -346,7 +357,7 @@ typedef struct ev2h_sa_branch {
     double radius;                      /* double: see ev2h_ball_query */
     const void* W2s; const void* W3s;   /* 16-bit tile images (NULL unless precision != F32) */
     float w2_unscale, w3_unscale;       /* see ev2h_sa_desc */
-    float w1x_norm, w2_norm, b2_max;    /* F16X2 range bounds as in ev2h_sa_desc; filled by pack.py */
+    float w1x_norm, w2_norm, b2_max;    /* F16X2 range bounds as in ev2h_sa_desc; filled by ev2h_pack_weights */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
@@ -387,9 +398,68 @@ typedef struct ev2h_weights {
     ev2h_dense head0[2], head4[2];
     int precision;                               /* EV2H_PREC_* used by the MFMA kernels               */
     const float* l0_unscale;                     /* [256] or NULL: ev2h_attn_context's value_unscale -- the per-channel powers of two
-                                                    the host's channel equalisation (pack.py: equalize_channels) multiplied fp1's
+                                                    the channel equalisation (ev2h_pack_weights) multiplied fp1's
                                                     output by; every other consumer of that tensor has them folded into its columns */
+    int flags;                                   /* EV2H_W_*                                            */
 } ev2h_weights;
+#define EV2H_W_EQUALIZED 1        /* the hidden channels were equalised by ev2h_pack_weights (the F16X2 accuracy contract above)  */
+#define EV2H_W_UNEQUALIZED_OK 2   /* the caller knows its F16X2 weights are not equalised and wants them run anyway               */
+
+/* ---- weight packing (host side): checkpoint -> the ev2h_weights a forward takes ---------------------------------------------
+ * Replaces what nn.Module.load_state_dict + eval-mode BatchNorm do for the reference (model/model.py:14-23, demo.py:83-84,
+ * pointnet2_utils.py:198,256,314, TEHNet.py:49-55,135-166): `tensors` are the checkpoint's entries as HOST arrays under the
+ * reference's own names (a leading "module." is ignored, model.py:16-21; `num_batches_tracked` entries are ignored); the
+ * schema is checked strictly (missing / unexpected key, wrong shape -> EV2H_ERR_ARG with the key in ev2h_last_error(), as
+ * load_state_dict(strict=True) raises).  The packer
+ *   1. folds eval-mode BatchNorm in float64 (Conv -> BN -> ReLU into W, b; Conv/Linear -> ReLU -> BN kept as a post-ReLU affine
+ *      except in the segmentation head, where it folds forward into the last k=1 convolution; Conv -> BN of the second query
+ *      convolution into W, b), rounded to fp32 once;
+ *   2. with EV2H_PACK_EQUALIZE multiplies every hidden channel by e_c = 2^round(log2 sqrt(|consumer columns c| / |producer
+ *      row c|)) at its producers and divides its consumers' columns by e_c (three sweeps; hidden tensors that share a
+ *      contraction with raw coordinates are brought level with those): exact powers of two, so the network function and every
+ *      fp32 partial sum are unchanged up to an exact scaling, and the F16X2 planes see well-conditioned operands;
+ *   3. lays the weights out as the kernels read them (layer-1 feature weights of all radius branches stacked, W2 rows padded
+ *      to 32, W3 columns to 8, group-all inputs as [features | xyz | 0], k=3 taps tap-major), splits them into the operand
+ *      planes of `precision` (ev2h_tile_geometry) and computes the F16X2 range bounds;
+ *   4. uploads everything into ONE device allocation on the current device, owned by the returned handle.
+ * The handle owns the memory ev2h_packed_weights() points into: free it only when no forward that uses it is in flight (and no
+ * captured graph refers to it). */
+typedef struct ev2h_tensor_desc {
+    const char* name;             /* checkpoint key                                                     */
+    const void* data;             /* HOST pointer, contiguous, row-major                                */
+    int dtype;                    /* EV2H_DT_*                                                          */
+    int ndim;
+    int64_t shape[4];
+} ev2h_tensor_desc;
+#define EV2H_DT_F32 0
+#define EV2H_DT_F64 1
+#define EV2H_DT_I64 2             /* accepted for num_batches_tracked only */
+#define EV2H_PACK_EQUALIZE 1      /* step 2 above; what every F16X2 user wants                                                   */
+#define EV2H_PACK_HOST_ONLY 2     /* no device: the weights view points into the handle's HOST copy (layout tests without a GPU)  */
+#define EV2H_PACK_UNEQUALIZED_OK 4 /* sets EV2H_W_UNEQUALIZED_OK in the view (explicit opt-out of the F16X2 contract)             */
+typedef struct ev2h_packed ev2h_packed;
+int ev2h_pack_weights(const ev2h_tensor_desc* tensors, int n, int in_channels, int precision, int flags, ev2h_packed** out);
+void ev2h_packed_free(ev2h_packed* p);
+const ev2h_weights* ev2h_packed_weights(const ev2h_packed* p);
+size_t ev2h_packed_bytes(const ev2h_packed* p);                 /* size of the device allocation */
+/* Introspection for tests and tools: the i-th packed array (0 <= i < ev2h_packed_tensor_count): name, [rows][cols], element type
+ * (EV2H_DT_F32, or -1 = bytes of a plane image), its HOST copy and its device address (NULL with EV2H_PACK_HOST_ONLY). */
+int ev2h_packed_tensor_count(const ev2h_packed* p);
+int ev2h_packed_tensor(const ev2h_packed* p, int i, const char** name, int* rows, int* cols, int* dtype, const void** host,
+                       const void** device);
+/* Equalisation factors of the i-th hidden tensor (0 <= i < ev2h_packed_equalization_count; 0 tensors without EV2H_PACK_EQUALIZE):
+ * e [n] powers of two, the accumulated factor channel c was multiplied by. */
+int ev2h_packed_equalization_count(const ev2h_packed* p);
+int ev2h_packed_equalization(const ev2h_packed* p, int i, const char** name, const double** e, int* n);
+/* The image builders on their own (operator-level callers of ev2h_sa_mlp_max / ev2h_fp_mlp / ev2h_gemm): W2 [C2][C1], W3 [C3][C2],
+ * W [N][K] row-major float64 on the HOST; img* = caller's HOST buffers of ev2h_pack_*_bytes bytes; u* = the power-of-two factor
+ * the planes were divided by (w2_unscale / w3_unscale / w_unscale).  planes: 1 BF16, 2 F16X2, 3 BF16X3. */
+int ev2h_pack_sa_image_bytes(int C1, int C2, int C3, int planes, size_t out[2]);
+int ev2h_pack_sa_images(const double* W2, const double* W3, int C1, int C2, int C3, int planes, void* img2, void* img3, float* u2,
+                        float* u3);
+size_t ev2h_pack_gemm_image_bytes(int N, int K, int planes, int tile_rows);
+int ev2h_pack_gemm_image(const double* W, int N, int K, int planes, int tile_rows, void* img, float* u);
+float ev2h_plane_unscale(const double* W, size_t count, int planes);
 
 typedef struct ev2h_outputs {
     float* class_logits;          /* [B,4,N]                                                           */

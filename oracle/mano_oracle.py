@@ -18,7 +18,16 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from ev2hands_amd.synth import MANO_JOINT_REORDER, MANO_TIPS
+# The oracle's OWN literal tables (not imported from the product package, so that the checker stays independent of what it
+# checks; tests/test_mano_oracle.py::test_tables_literal compares the two):
+#  * fingertip vertices appended to the 16 regressed joints -- manopth/manolayer.py ManoLayer.forward, `side == 'right'`:
+#    tips = th_verts[:, [745, 317, 444, 556, 673]], left: [745, 317, 445, 556, 673];
+#  * the reorder of the 21 joints to the "standard" hand-joint order, same file:
+#    th_jtr = th_jtr[:, [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]];
+#  * the kinematic chain: three levels below the root (lev1 = joints 1,4,7,10,13 ...) and the reorder [0, 1, 6, 11, ...] that
+#    puts the level-major results back into joint order.
+MANO_TIPS = {"right": [745, 317, 444, 556, 673], "left": [745, 317, 445, 556, 673]}
+MANO_JOINT_REORDER = [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
 
 LEVELS = ([1, 4, 7, 10, 13], [2, 5, 8, 11, 14], [3, 6, 9, 12, 15])
 CHAIN_REORDER = [0, 1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 5, 10, 15]

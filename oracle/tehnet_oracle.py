@@ -198,10 +198,8 @@ def query_conv(sd, side, x):
 
 def mano_params(sd, side, xyz_cm, feat_cm, init=None, trace=None):
     """TEHNet.py:68-90: MSG set abstraction on all N points, group-all, FC head -> [B,22]."""
-    from ev2hands_amd import synth as S
     p = f"{side}_mano_regressor"
-    l1_xyz, l1 = sa_msg(sd, p + ".sa1", xyz_cm, feat_cm, S.MANO_SA1_NPOINT, S.MANO_SA1_RADII, S.MANO_SA1_NSAMPLE,
-                        init, trace)
+    l1_xyz, l1 = sa_msg(sd, p + ".sa1", xyz_cm, feat_cm, 128, [0.4, 0.8], [64, 128], init, trace)      # TEHNet.py:43
     _, l2 = sa_group_all(sd, p + ".sa2", l1_xyz, l1)
     h = l2.squeeze(-1)
     h = F.relu(F.linear(h, sd[p + ".mano_regressor.0.weight"], sd[p + ".mano_regressor.0.bias"]))
@@ -215,14 +213,13 @@ def tehnet_forward(sd, xyz_in, mano_hands, fps_init=None, n_pose=6, training=Fal
     left.sa1, right.sa1); None draws them from the global RNG like the reference.
     `mano_hands[side](global_orient=, hand_pose=, betas=, transl=)` -> obj(.vertices, .joints)."""
     import numpy as np
-    from ev2hands_amd import synth as S
     fi = fps_init if fps_init is not None else [None] * 4
     feat0 = xyz_in
     xyz0 = xyz_in[:, :3, :]
     if mhlnes:
         xyz0[:, -1, :] = xyz_in[:, 3:, :].mean(1)        # in place, like TEHNet.py:176-177
-    l1_xyz, l1 = sa_msg(sd, "sa1", xyz0, feat0, S.SA1_NPOINT, S.SA1_RADII, S.SA1_NSAMPLE, fi[0], trace)
-    l2_xyz, l2 = sa_msg(sd, "sa2", l1_xyz, l1, S.SA2_NPOINT, S.SA2_RADII, S.SA2_NSAMPLE, fi[1], trace)
+    l1_xyz, l1 = sa_msg(sd, "sa1", xyz0, feat0, 512, [0.1, 0.2, 0.4], [32, 64, 128], fi[0], trace)      # TEHNet.py:128
+    l2_xyz, l2 = sa_msg(sd, "sa2", l1_xyz, l1, 128, [0.4, 0.8], [64, 128], fi[1], trace)               # TEHNet.py:128
     l3_xyz, l3 = sa_group_all(sd, "sa3", l2_xyz, l2)
     if trace is not None:
         trace.update({"sa1_points": l1, "sa2_points": l2})

@@ -14,6 +14,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import stress_checkpoints as sc  # noqa: E402
 from ev2hands_amd import synth  # noqa: E402
 from ev2hands_amd.model import TEHNetWrapper  # noqa: E402
 
@@ -62,13 +64,13 @@ def main():
             continue
         sd = synth.synth_state_dict(C, seed)
         if variant == "channels":
-            sd = synth.rescale_channels(sd, [3, 8, 14][int(p1 * 3)], seed, include_l0=p2 < 0.5)
+            sd = sc.rescale_channels(sd, [3, 8, 14][int(p1 * 3)], seed, include_l0=p2 < 0.5)
         elif variant == "dead":
-            sd = synth.rescale_channels(sd, 4, seed, dead_fraction=0.15)
+            sd = sc.rescale_channels(sd, 4, seed, dead_fraction=0.15)
         elif variant == "heavy":
-            sd = synth.heavy_tailed(sd, [1.0, 2.0][int(p1 * 2)], seed)
+            sd = sc.heavy_tailed(sd, [1.0, 2.0][int(p1 * 2)], seed)
         elif variant == "hidden":
-            sd = synth.rescale_hidden(sd, [1e-4, 1e3, 1e6][int(p1 * 3)])
+            sd = sc.rescale_hidden(sd, [1e-4, 1e3, 1e6][int(p1 * 3)])
         os.environ["ERPC"] = "1" if C == 5 else "0"
         os.environ["MHLNES"] = str(mh)
         assets = {s: synth.synth_mano_assets(s, seed % 7) for s in ("left", "right")}
@@ -81,7 +83,7 @@ def main():
         #  and its own result is ill-defined)
         inp = ["plain", "plain", "hot", "counts"][int(p2 * 4)] if (C == 5 and not mh) else "plain"
         if inp == "hot":                                     # a hot pixel: 1e2 .. 1e6 events in one point per window
-            xyz = synth.add_outlier_points(xyz, 10.0 ** (2 + 4 * p1), channel=3, per_window=1, seed=seed)
+            xyz = sc.add_outlier_points(xyz, 10.0 ** (2 + 4 * p1), channel=3, per_window=1, seed=seed)
         elif inp == "counts":                                # all event counts 100 x larger
             xyz[:, 3:] *= 100.0
         variant = variant + "/" + inp

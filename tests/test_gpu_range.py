@@ -3,7 +3,7 @@
 fp16 planes overflow at 65504 and go subnormal below 6e-5, so the two-plane split is only fp32-class when its operands sit in a
 good part of that range.  The library keeps a per-window maximum of every tensor a contraction reads and scales by exact powers of
 two; these tests drive it with checkpoints whose hidden activations are 1e-4 ... 1e+6 times the usual O(1) (the network function
-is unchanged: synth.rescale_hidden) and require the same parity bar as everywhere else -- 1e-4 relative on every output against
+is unchanged: sc.rescale_hidden) and require the same parity bar as everywhere else -- 1e-4 relative on every output against
 the oracle, segmentation argmax and every FPS / ball-query / 3-NN selection identical."""
 import os
 
@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import stress_checkpoints as sc
 from ev2hands_amd import synth
 from test_gpu_forward import _need_gpu, check_against, rel, run_oracle
 
@@ -35,7 +36,7 @@ def test_hidden_activation_magnitude_does_not_matter(alpha, precision):
     high planes at and beyond the fp16 maximum (65504)."""
     _need_gpu()
     C, N, B, seed = 4, 1024, 2, 11
-    sd = synth.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
+    sd = sc.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
     net, assets = _net(C, sd, seed, precision)
     xyz = synth.synth_cloud("E", B, C, N, seed)
     inits = synth.fps_inits(B, N, seed)
@@ -56,7 +57,7 @@ def test_windows_of_one_batch_are_scaled_independently(alpha):
     exactly as when it is run alone (the scales are per window, so sharding a batch never changes a result)."""
     _need_gpu()
     C, N, seed = 5, 512, 12
-    sd = synth.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
+    sd = sc.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
     net, assets = _net(C, sd, seed, "f16x2")
     xyz = synth.synth_cloud("E", 3, C, N, seed)
     xyz[1, 3:] *= 1e4                                   # event counts of window 1: far larger than its neighbours'
@@ -198,7 +199,7 @@ def test_per_channel_scales_do_not_matter(log2_spread, precision):
     well-conditioned representation (without it f16x2 degrades from 2^+-8 on: see the report test below)."""
     _need_gpu()
     C, N, B, seed = 4, 1024, 2, 21
-    sd = synth.rescale_channels(synth.synth_state_dict(C, seed), log2_spread, seed)
+    sd = sc.rescale_channels(synth.synth_state_dict(C, seed), log2_spread, seed)
     out, net, ref, trace = _run_case(sd, C, N, B, seed, precision)
     assert _channel_spread(trace["sa1_points"]) > 1.5 * log2_spread               # the spread is really there in the reference
     check_against(out, net, ref, trace, B, N)
@@ -209,7 +210,7 @@ def test_per_channel_scales_including_the_attention_value(precision):
     """The same with fp1's output (classifier / query-convolution input AND the attention's value) spread over 2^16."""
     _need_gpu()
     C, N, B, seed = 5, 1024, 2, 26
-    sd = synth.rescale_channels(synth.synth_state_dict(C, seed), 8, seed, include_l0=True)
+    sd = sc.rescale_channels(synth.synth_state_dict(C, seed), 8, seed, include_l0=True)
     out, net, ref, trace = _run_case(sd, C, N, B, seed, precision)
     assert _channel_spread(trace["l0_points"]) > 12
     assert net.net.packed("cuda:0").struct.l0_unscale                              # the value path really carries factors
@@ -221,7 +222,7 @@ def test_dead_channels_and_per_channel_scales(precision):
     """10 % of the hidden channels are dead units (gamma = 0: the channel is the constant relu(beta)) on top of a 2^+-5 spread."""
     _need_gpu()
     C, N, B, seed = 5, 1024, 2, 22
-    sd = synth.rescale_channels(synth.synth_state_dict(C, seed), 5, seed, dead_fraction=0.1)
+    sd = sc.rescale_channels(synth.synth_state_dict(C, seed), 5, seed, dead_fraction=0.1)
     out, net, ref, trace = _run_case(sd, C, N, B, seed, precision)
     check_against(out, net, ref, trace, B, N)
 
@@ -231,7 +232,7 @@ def test_heavy_tailed_weights(precision):
     """Log-normal weight magnitudes (sigma 1.5: the largest weight of a layer is hundreds of times its median)."""
     _need_gpu()
     C, N, B, seed = 4, 1024, 2, 23
-    sd = synth.heavy_tailed(synth.synth_state_dict(C, seed), 1.5, seed)
+    sd = sc.heavy_tailed(synth.synth_state_dict(C, seed), 1.5, seed)
     out, net, ref, trace = _run_case(sd, C, N, B, seed, precision)
     check_against(out, net, ref, trace, B, N)
 
@@ -244,7 +245,7 @@ def test_hot_pixel_in_the_input(count, precision):
     _need_gpu()
     C, N, B, seed = 5, 1024, 2, 24
     sd = synth.synth_state_dict(C, seed)
-    xyz = synth.add_outlier_points(synth.synth_cloud("E", B, C, N, seed), count, channel=3, per_window=1, seed=seed)
+    xyz = sc.add_outlier_points(synth.synth_cloud("E", B, C, N, seed), count, channel=3, per_window=1, seed=seed)
     out, net, ref, trace = _run_case(sd, C, N, B, seed, precision, xyz=xyz)
     check_against(out, net, ref, trace, B, N)
 
@@ -255,7 +256,7 @@ def test_equalisation_does_not_change_the_exact_fp32_result():
     function.  Checked on a plain and on a 2^+-8 rescaled checkpoint."""
     _need_gpu()
     C, N, B, seed = 4, 640, 2, 27
-    for sd in (synth.synth_state_dict(C, seed), synth.rescale_channels(synth.synth_state_dict(C, seed), 8, seed)):
+    for sd in (synth.synth_state_dict(C, seed), sc.rescale_channels(synth.synth_state_dict(C, seed), 8, seed)):
         outs = []
         for eq in (False, True):
             net, _ = _net(C, sd, seed, "f32", equalize=eq)
@@ -276,7 +277,7 @@ def test_without_equalisation_the_degradation_is_reported(log2_spread, capsys):
     exponent bits) hold the full bar with or without equalisation."""
     _need_gpu()
     C, N, B, seed = 4, 1024, 2, 25
-    sd = synth.rescale_channels(synth.synth_state_dict(C, seed), log2_spread, seed)
+    sd = sc.rescale_channels(synth.synth_state_dict(C, seed), log2_spread, seed)
     report = {}
     for precision in ("f32", "bf16x3", "f16x2"):
         out, net, ref, trace = _run_case(sd, C, N, B, seed, precision, equalize=False)
@@ -300,7 +301,7 @@ def test_hot_pixel_beyond_the_range_of_one_window_is_reported(count, capsys):
     _need_gpu()
     C, N, B, seed = 5, 1024, 2, 28
     sd = synth.synth_state_dict(C, seed)
-    xyz = synth.add_outlier_points(synth.synth_cloud("E", B, C, N, seed), count, channel=3, per_window=1, seed=seed)
+    xyz = sc.add_outlier_points(synth.synth_cloud("E", B, C, N, seed), count, channel=3, per_window=1, seed=seed)
     report = {}
     for precision in ("f32", "bf16x3", "f16x2"):
         out, net, ref, trace = _run_case(sd, C, N, B, seed, precision, xyz=xyz)

@@ -31,11 +31,11 @@ def test_library_exports_every_declared_symbol(built):
 
 
 def test_struct_layouts_and_abi_version(built):
-    sizes = (C.c_size_t * 7)()
+    sizes = (C.c_size_t * 8)()
     built.ev2h_struct_sizes(sizes)
-    mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc)]
+    mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc, _lib.TensorDesc)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 5
+    assert built.ev2h_abi_version() == 6 == _lib.ABI_VERSION
 
 
 def test_workspace_size_grows_linearly(built):
@@ -174,8 +174,8 @@ def test_mano_pkl_reader_without_chumpy(tmp_path):
 
 def test_tile_geometry_comes_from_the_kernels(built):
     """One source of truth for the weight tile images: the library exports the kernels' compile-time geometry and
-    pack.py's image builders assert their own numbers against it on every pack; a drift raises at load time, not in a GPU parity
-    test.  No GPU needed."""
+    its packer (csrc/pack.hip) asserts its own numbers against it on every pack, as does the numpy restatement tests/ref_pack.py;
+    a drift raises at pack time, not in a GPU parity test.  No GPU needed."""
     import ctypes as C
     from ev2hands_amd import pack
     out = (C.c_int * 10)()
@@ -189,14 +189,15 @@ def test_tile_geometry_comes_from_the_kernels(built):
             i2, i3, u2, u3 = pack.sa_bf16_images(rng.normal(size=(c2, c1)), rng.normal(size=(c3, c2)), ns)     # asserts inside
             g = pack.kernel_geometry(c1, c2, c3, ns)
             assert i2.size == (c1 // 32) * g["TB2"] and i3.size == (c3 // 32) * g["TB3"]
-    # a drifted packer is caught
-    real = pack.sa_bf16_geometry
-    pack.sa_bf16_geometry = lambda C2: (real(C2)[0], real(C2)[1] + 16)
+    # a drifted packer is caught (shown on the restatement, whose geometry function can be patched; the C packer runs the same check)
+    import ref_pack
+    real = ref_pack.sa_bf16_geometry
+    ref_pack.sa_bf16_geometry = lambda C2: (real(C2)[0], real(C2)[1] + 16)
     try:
         with pytest.raises(Exception, match="tile geometry"):
-            pack.sa_bf16_images(rng.normal(size=(196, 128)), rng.normal(size=(256, 196)), 2)
+            ref_pack.sa_bf16_images(rng.normal(size=(196, 128)), rng.normal(size=(256, 196)), 2)
     finally:
-        pack.sa_bf16_geometry = real
+        ref_pack.sa_bf16_geometry = real
 
 
 # ---- real-asset hardening: the day MANO_{LEFT,RIGHT}.pkl and best_model_state_dict.pth appear -----------------

@@ -128,6 +128,8 @@ def test_tables_literal():
     assert synth.MANO_TIPS["left"] == [745, 317, 445, 556, 673]
     assert synth.MANO_JOINT_REORDER == [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20]
     assert mano_oracle.CHAIN_REORDER == [0, 1, 6, 11, 2, 7, 12, 3, 8, 13, 4, 9, 14, 5, 10, 15]
+    # the oracle keeps its own literal copies (it does not import the product's): the two must agree
+    assert mano_oracle.MANO_TIPS == synth.MANO_TIPS and mano_oracle.MANO_JOINT_REORDER == synth.MANO_JOINT_REORDER
 
 
 def test_left_shapedirs_fix():

@@ -1,10 +1,12 @@
 """CPU: the host-side pieces of the f16x2 range handling and of the stress inputs -- plane split and power-of-two scale as the
-kernels apply them (csrc/planes.hpp), the bounds pack.py hands to the kernels, and the test helpers themselves
-(synth.rescale_hidden must not change the network function; oracle/stress.py must really produce near-ties)."""
+kernels apply them (csrc/planes.hpp), the bounds the packer hands to the kernels, and the test helpers themselves
+(sc.rescale_hidden must not change the network function; oracle/stress.py must really produce near-ties)."""
 import numpy as np
 import pytest
 import torch
 
+import ref_pack
+import stress_checkpoints as sc
 from ev2hands_amd import pack, synth
 
 
@@ -35,7 +37,7 @@ def test_two_plane_split_is_fp32_class_inside_the_scaled_range():
     x = (rng.uniform(-1, 1, 200000) * np.exp(rng.uniform(np.log(1e-9), 0, 200000))).astype(np.float32) * amax
     s = f16x2_scale(amax)
     xs = x * s
-    h, l = pack.split_bf16_planes(xs, 2)
+    h, l = ref_pack.split_bf16_planes(xs, 2)
     rec = h.view(np.float16).astype(np.float64) + l.view(np.float16).astype(np.float64)
     err = np.abs(rec - xs.astype(np.float64))
     big = np.abs(xs) >= 2.0 ** -3
@@ -43,7 +45,7 @@ def test_two_plane_split_is_fp32_class_inside_the_scaled_range():
     assert np.all(err[~big] <= 2.0 ** -25)
     assert np.isfinite(h.view(np.float16)).all() and np.isfinite(l.view(np.float16)).all()
     # unscaled, the same values lose their low plane to fp16 subnormals (the round-1 weakness)
-    h0, l0 = pack.split_bf16_planes(x, 2)
+    h0, l0 = ref_pack.split_bf16_planes(x, 2)
     rec0 = h0.view(np.float16).astype(np.float64) + l0.view(np.float16).astype(np.float64)
     rel0 = np.abs(rec0 - x.astype(np.float64)) / np.maximum(np.abs(x), 1e-30)
     assert np.median(rel0[np.abs(x) > amax / 8]) > 2.0 ** -16
@@ -78,7 +80,7 @@ def test_rescale_hidden_keeps_the_network_function(alpha):
     ta, tb = {}, {}
     with torch.no_grad():
         a = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=ta)
-        b = tehnet_oracle.tehnet_forward(synth.rescale_hidden(sd, alpha), xyz.clone(), hands, fps_init=inits, trace=tb)
+        b = tehnet_oracle.tehnet_forward(sc.rescale_hidden(sd, alpha), xyz.clone(), hands, fps_init=inits, trace=tb)
     rel = lambda x, y: float((x - y).abs().max() / y.abs().max())           # noqa: E731
     assert rel(b["class_logits"], a["class_logits"]) < 5e-6 and rel(b["left"]["vertices"], a["left"]["vertices"]) < 5e-6
     for k in ("l0_points", "l1_points", "l2_points"):                       # hidden tensors really are alpha times larger
@@ -101,11 +103,13 @@ def test_near_tie_head_produces_near_ties():
     assert len(torch.unique(tied["class_logits"].argmax(1))) >= 3           # and the classes really alternate
 
 
-# ------------------------------------------------------------------------------------------------ channel equalisation (pack.py)
+# ------------------------------------------------------------------------------------------------ channel equalisation
+# (properties of the algorithm, checked on the numpy restatement tests/ref_pack.py; tests/test_pack_abi.py requires the library's
+# packer, csrc/pack.hip, to reproduce that restatement -- factors and packed bytes -- exactly)
 def _layer_spread(F):
     """worst log2(max / min) over the hidden tensors of (row norm of the producer) and of (column norm of a consumer)"""
     worst_r = worst_c = 0.0
-    for _, producers, consumers in pack.hidden_tensors():
+    for _, producers, consumers in ref_pack.hidden_tensors():
         r = np.concatenate([np.sqrt((F[l]["W"].reshape(F[l]["W"].shape[0], -1) ** 2).sum(1) + F[l]["b"] ** 2) *
                             (np.abs(F[l]["ps"]) if k == "post" else 1.0) for l, k in producers])
         n = r.shape[0]
@@ -118,9 +122,9 @@ def _layer_spread(F):
 
 
 def test_hidden_tensor_table_matches_the_checkpoint_schema():
-    F = pack.fold_checkpoint(synth.synth_state_dict(5, 2))
+    F = ref_pack.fold_checkpoint(synth.synth_state_dict(5, 2))
     seen_rows, seen_cols = set(), {}
-    for name, producers, consumers in pack.hidden_tensors():
+    for name, producers, consumers in ref_pack.hidden_tensors():
         n = sum(F[l]["W"].shape[0] for l, _ in producers)
         for l, _ in producers:
             assert l not in seen_rows, l                       # every layer's rows belong to exactly one tensor
@@ -142,15 +146,15 @@ def test_hidden_tensor_table_matches_the_checkpoint_schema():
 
 @pytest.mark.parametrize("log2_spread", [8, 16])
 def test_equalisation_undoes_per_channel_rescaling(log2_spread):
-    """A checkpoint whose hidden channels were rescaled by 2^+-s (synth.rescale_channels: same network, other representative)
+    """A checkpoint whose hidden channels were rescaled by 2^+-s (sc.rescale_channels: same network, other representative)
     packs to an equally well-conditioned representation: the accumulated factors absorb the rescaling up to the power-of-
     two rounding, and the row / column spreads the 16-bit planes see are those of the original checkpoint, not 2^(2s)."""
     sd = synth.synth_state_dict(4, 9)
-    F0 = pack.fold_checkpoint(sd)
-    F1 = pack.fold_checkpoint(synth.rescale_channels(sd, log2_spread, 9))
+    F0 = ref_pack.fold_checkpoint(sd)
+    F1 = ref_pack.fold_checkpoint(sc.rescale_channels(sd, log2_spread, 9))
     r_raw, c_raw = _layer_spread(F1)
     assert r_raw > 1.5 * log2_spread and c_raw > 1.5 * log2_spread
-    e0, e1 = pack.equalize_channels(F0), pack.equalize_channels(F1)
+    e0, e1 = ref_pack.equalize_channels(F0), ref_pack.equalize_channels(F1)
     for k, e in e1.items():
         assert np.all(np.log2(e) == np.round(np.log2(e))), k                          # exact powers of two
     r_eq, c_eq = _layer_spread(F1)
