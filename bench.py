@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--no-legs", "--no-f32-leg", dest="no_legs", action="store_true", help="skip the timing legs of the other arithmetic modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the two-stream / gather self-checks after the timed region")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live HBM-traffic measurement (two rocprofv3 PMC passes of a 3-step child run of this script)")
     ap.add_argument("--collision", action="store_true",
@@ -218,7 +219,7 @@ def live_pmc_traffic(a, timeout_s=300):
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     nsteps = 3
-    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic",
+    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck",
              "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud]
     tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
@@ -228,7 +229,7 @@ def live_pmc_traffic(a, timeout_s=300):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             # the program itself follows `--` (no env / shell / launcher hop: the profiler's preloaded library has initialised the GPU)
-            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", "python3"] + child, cwd="/tmp", env=env,
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", os.path.realpath(sys.executable)] + child, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -337,6 +338,9 @@ def run_rank(a) -> int:
     import torch
     from ev2hands_amd import dist as evdist, synth
 
+    # dmabuf IPC: RCCL / cross-process device memory on this driver need it; also for ranks started by torch.distributed.run,
+    # which does not go through launch_ranks() -- set before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -458,7 +462,17 @@ def run_rank(a) -> int:
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        timed.local = dt_
         return float(tmax.item())
+
+    def all_ranks(value):
+        """[value of rank 0, ..., value of rank world-1] on every rank"""
+        t = torch.tensor([float(value)], device=dev, dtype=torch.float64)
+        if not use_dist:
+            return [float(t.item())]
+        full = torch.zeros(world_seen, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(full, t)
+        return [float(v) for v in full.tolist()]
 
     last = None
     for _ in range(a.warmup):
@@ -470,6 +484,46 @@ def run_rank(a) -> int:
     if L is not None:
         L.ev2h_profile_set(None, None, None, 0)
     main_kernel_ms = ev.elapsed_ms(a.steps) if ev is not None else []
+    rank_ms = [round(v / a.steps * 1e3, 3) for v in all_ranks(timed.local)]        # every rank's own wall time per step
+
+    # self-checks of the multi-GPU run (outside the timed region; every rank takes part):
+    #  * two_stream_gain: a few steps with the library's side stream switched off (ev2h_set_side_stream) against the same number
+    #    with it on -- a rank whose side stream shares a hardware queue with its main stream shows ~1.00
+    #    where the others show ~1.05, without any error;
+    #  * gather_ms: the all-gather alone (device time between two events around a blocking collective on an idle device).
+    selfcheck = None
+    if not a.stub and not a.no_selfcheck:
+        k = max(3, min(a.steps // 10, 10))
+        timed(2)                                          # (back to steady clocks after the profiling hook)
+        t_on = timed(k); on_local = timed.local
+        prev = L.ev2h_set_side_stream(0)
+        timed(2)
+        t_off = timed(k); off_local = timed.local
+        L.ev2h_set_side_stream(prev)
+        timed(2)
+        gains = [round(v, 4) for v in all_ranks(off_local / on_local)]
+        selfcheck = {"two_stream_gain": round(t_off / t_on, 4), "two_stream_gain_per_rank": gains, "steps_each": k,
+                     "note": "wall time of k steps with ev2h_set_side_stream(0) / with the default two-stream schedule; ~1.00 on a rank "
+                             "means its side stream shares a hardware queue with the main stream"}
+        if pipe is not None:
+            b0 = pipe.bufs[0]
+            lo_ = b0.rank * b0.big
+            gms = []
+            for _ in range(7):
+                torch.cuda.synchronize()
+                if use_dist:
+                    dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_gather_into_tensor(b0.full, b0.full[lo_:lo_ + b0.big])
+                e1.record()
+                torch.cuda.synchronize()
+                gms.append(e0.elapsed_time(e1))
+            gms.sort()
+            selfcheck["gather_ms"] = round(gms[len(gms) // 2], 4)
+            selfcheck["gather_ms_per_rank"] = [round(v, 4) for v in all_ranks(gms[len(gms) // 2])]
+            selfcheck["gather_bytes_received_per_rank_per_step"] = int((world_seen - 1) * b0.big * b0.full.shape[1] * 4)
+            selfcheck["gather_buffer_bytes"] = int(b0.full.numel() * 4)
 
     # transparency legs: the same workload in the other arithmetic modes (not part of `value`)
     legs, leg_kernel_ms = {}, {}
@@ -536,6 +590,14 @@ def run_rank(a) -> int:
                 t, src = committed_pmc_traffic(a.precision)
                 if t is not None:
                     live, live_src = t, (live_src + "; " if live_src else "") + f"committed profile profiles/{src} (not measured in this run)"
+            res["ms_per_step_per_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
+            if selfcheck:
+                res["multi_gpu_selfcheck"] = selfcheck
+            if use_dist:
+                try:
+                    res["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:  # noqa: BLE001
+                    res["config"]["rccl_version"] = None
             res["roofline"] = roofline_entry(a.precision, B, main_kernel_ms, live["kernel"] if live else None, live_src)
             res["hbm"] = hbm_entry(B, N, dt / a.steps * 1e3, live.get("step") if live else None, live_src)
             f32_leg = legs.pop("f32", None)

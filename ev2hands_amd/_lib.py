@@ -93,13 +93,13 @@ class Outputs(C.Structure):
 
 
 EXPORTS = [
-    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_struct_sizes",
+    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
-    "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set",
+    "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set", "ev2h_range_report_entries", "ev2h_range_report",
     "ev2h_pack_weights", "ev2h_packed_free", "ev2h_packed_weights", "ev2h_packed_bytes", "ev2h_packed_tensor_count", "ev2h_packed_tensor",
-    "ev2h_packed_equalization_count", "ev2h_packed_equalization", "ev2h_pack_sa_image_bytes", "ev2h_pack_sa_images",
+    "ev2h_packed_equalization_count", "ev2h_packed_equalization", "ev2h_packed_weight_spread_count", "ev2h_packed_weight_spread", "ev2h_pack_sa_image_bytes", "ev2h_pack_sa_images",
     "ev2h_pack_gemm_image_bytes", "ev2h_pack_gemm_image", "ev2h_plane_unscale",
     "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
 ]
@@ -130,6 +130,7 @@ def lib() -> C.CDLL:
     L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
     L.ev2h_struct_sizes.restype = None
     L.ev2h_struct_sizes.argtypes = [C.c_size_t * 8]
+    L.ev2h_set_side_stream.argtypes = [ci]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -155,6 +156,8 @@ def lib() -> C.CDLL:
     L.ev2h_joint_metrics.argtypes = [vp, vp, vp, ci, ci, ci, C.c_double, vp, vp, vp, vp, vp, vp]
     L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp]
     L.ev2h_collision_penalty.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, C.c_double, vp, vp, ci, vp, vp]
+    L.ev2h_range_report_entries.argtypes = [C.POINTER(C.c_char_p), ci]
+    L.ev2h_range_report.argtypes = [vp, ci, ci, vp, vp]
     L.ev2h_profile_set.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(vp), ci]
     L.ev2h_pack_weights.argtypes = [C.POINTER(TensorDesc), ci, ci, ci, ci, C.POINTER(vp)]
     L.ev2h_packed_free.restype = None
@@ -167,6 +170,8 @@ def lib() -> C.CDLL:
     L.ev2h_packed_tensor.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(vp), C.POINTER(vp)]
     L.ev2h_packed_equalization_count.argtypes = [vp]
     L.ev2h_packed_equalization.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(ci)]
+    L.ev2h_packed_weight_spread_count.argtypes = [vp]
+    L.ev2h_packed_weight_spread.argtypes = [vp, ci, C.POINTER(C.c_char_p), C.c_uint64 * 3]
     L.ev2h_pack_sa_image_bytes.argtypes = [ci, ci, ci, ci, C.c_size_t * 2]
     L.ev2h_pack_sa_images.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ev2h_pack_gemm_image_bytes.restype = C.c_size_t

@@ -1,12 +1,14 @@
 // ev2h_forward: TEHNet.forward (/root/reference/src/Ev2Hands/model/TEHNet.py:168-197) as one
 // in-order sequence of gfx950 kernels on a caller-provided stream and workspace.  No allocation,
 // no host synchronisation, no device->host copies inside (hipGraph-capturable).
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
+#include "planes.hpp"
 #include "ev2hands_hip.h"
 
 int ev2h_gemm_init();
@@ -95,6 +97,14 @@ struct SideCtx {
 };
 constexpr int EV2H_MAX_DEVICES = 16;
 static thread_local SideCtx g_side[EV2H_MAX_DEVICES];
+
+static thread_local int g_side_disabled = 0;      // ev2h_set_side_stream(0): run everything on the caller's stream (per host thread)
+
+extern "C" int ev2h_set_side_stream(int enabled) {
+    const int prev = !g_side_disabled;
+    g_side_disabled = !enabled;
+    return prev;
+}
 
 static SideCtx* side_ctx() {     // the current device's side stream, or nullptr (single-stream mode)
     int dev = 0;
@@ -349,6 +359,101 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------- F16X2 spread report
+// The operand tensors of the F16X2 contractions that are MATERIALISED in the workspace, as their consumers read them: buffer,
+// rows per window, row stride, column range, and the range record(s) the consumer derives its power-of-two scale from (two
+// records: the consumer takes their maximum -- a concatenated input).  Not listed: operands that never reach memory (the hidden
+// layers inside the fused set-abstraction / row-chain kernels, whose scales come from bounds): TEHNet.verify_precision compares
+// whole forwards for those.
+struct SpreadEntry { const char* name; const char* buf; int rows; int ld; int col0; int ncols; int rec; int rec2; size_t hand_off; };
+
+static int spread_entries(int N, SpreadEntry* e) {      // rows == 0: N rows per window
+    int n = 0;
+    e[n++] = {"feat", "feat8", 0, 8, 0, 8, R_FEAT, -1, 0};
+    e[n++] = {"l1", "l1cat", 512, 576, 0, 320, R_L1A, -1, 0};
+    e[n++] = {"l1cat", "l1cat", 512, 576, 0, 576, R_L1A, R_L1B, 0};
+    e[n++] = {"l2", "l2buf", 128, 520, 0, 515, R_L2, R_FEAT, 0};
+    e[n++] = {"sa3h1", "sa3h1", 128, 256, 0, 256, R_SA3H1, -1, 0};
+    e[n++] = {"sa3h2", "sa3h2", 128, 512, 0, 512, R_SA3H2, -1, 0};
+    e[n++] = {"l3", "l3", 1, 1024, 0, 1024, R_L3, -1, 0};
+    e[n++] = {"fp3h", "fp3h", 128, 256, 0, 256, R_FP3H, -1, 0};
+    e[n++] = {"fp3o", "fp3o", 128, 256, 0, 256, R_FP3O, -1, 0};
+    e[n++] = {"fp2h", "fp2h", 512, 256, 0, 256, R_FP2H, -1, 0};
+    e[n++] = {"l1new", "l1new", 512, 128, 0, 128, R_L1NEW, -1, 0};
+    e[n++] = {"l0", "l0", 0, 256, 0, 256, R_L0, -1, 0};
+    for (int h = 0; h < 2; ++h) {
+        e[n++] = {h ? "hfR" : "hfL", "hf8", 0, 8, 0, 8, R_HF + h, -1, (size_t)h};
+        e[n++] = {h ? "m1R" : "m1L", kHandNames[h][6], 128, 520, 0, 515, R_M1 + h, R_FEAT, 0};
+        e[n++] = {h ? "msa2hR" : "msa2hL", kHandNames[h][7], 128, 256, 0, 256, R_MSA2H + h, -1, 0};
+        e[n++] = {h ? "m2R" : "m2L", kHandNames[h][8], 1, 512, 0, 512, R_M2 + h, -1, 0};
+        e[n++] = {h ? "fc1R" : "fc1L", kHandNames[h][9], 1, 1024, 0, 1024, R_FC1 + h, -1, 0};
+    }
+    (void)N;
+    return n;
+}
+constexpr int EV2H_MAX_SPREAD = 32;
+
+namespace {
+// counts[b] = {non-zero values, values with 0 < |v| s < 2^-3 (low fp16 plane subnormal: fewer than 22 bits survive the split),
+// values with 0 < |v| s < 2^-14 (high plane subnormal too: fewer than 11 bits)}, s = the consumer's power-of-two scale
+__global__ __launch_bounds__(256) void spread_count_kernel(const float* __restrict__ buf, size_t window_stride, int rows, int ld, int col0, int ncols,
+                                                           const unsigned* __restrict__ rec, const unsigned* __restrict__ rec2,
+                                                           unsigned* __restrict__ counts) {
+    const int b = blockIdx.y;
+    unsigned a = rec[b];
+    if (rec2) a = max(a, rec2[b]);
+    const float s = f16x2_scale(a);
+    const float* base = buf + (size_t)b * window_stride;
+    const size_t total = (size_t)rows * ncols;
+    unsigned nz = 0, lo = 0, hi = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / ncols;
+        const int c = (int)(i - r * ncols);
+        const float v = fabsf(base[r * ld + col0 + c]) * s;
+        nz += v > 0.f;
+        lo += v > 0.f && v < 0.125f;
+        hi += v > 0.f && v < 6.103515625e-05f;
+    }
+    nz = (unsigned)wave_sum_f32((float)nz); lo = (unsigned)wave_sum_f32((float)lo); hi = (unsigned)wave_sum_f32((float)hi);   // < 2^24 per wave: exact
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[(size_t)b * 3 + 0], nz);
+        atomicAdd(&counts[(size_t)b * 3 + 1], lo);
+        atomicAdd(&counts[(size_t)b * 3 + 2], hi);
+    }
+}
+}  // namespace
+
+extern "C" int ev2h_range_report_entries(const char** names, int max_names) {
+    SpreadEntry e[EV2H_MAX_SPREAD];
+    const int n = spread_entries(2048, e);
+    for (int i = 0; i < n && names && i < max_names; ++i) names[i] = e[i].name;
+    return n;
+}
+
+extern "C" int ev2h_range_report(void* workspace, int B, int N, uint32_t* counts, ev2h_stream_t st) {
+    EV2H_CHECK_ARG(workspace && counts && B > 0 && N >= 128 && N <= 32768);
+    Ws ws;
+    ws.base = static_cast<char*>(workspace);
+    ws.B = B;
+    ws.ranges_on = true;
+    build_layout(ws.L, B, N);
+    SpreadEntry e[EV2H_MAX_SPREAD];
+    const int n = spread_entries(N, e);
+    EV2H_CHECK_HIP(hipMemsetAsync(counts, 0, (size_t)n * B * 3 * sizeof(uint32_t), (hipStream_t)st));
+    for (int i = 0; i < n; ++i) {
+        const Buf* bf = ws.L.find(e[i].buf);
+        EV2H_CHECK_ARG(bf != nullptr);
+        const int rows = e[i].rows ? e[i].rows : N;
+        const float* p = reinterpret_cast<const float*>(ws.base + bf->off) + e[i].hand_off * (size_t)B * N * 8;      // hf8: [2][B * N][8]
+        const size_t per_window = (size_t)rows * e[i].ld;
+        const int gx = (int)std::min<size_t>(64, ((size_t)rows * e[i].ncols + 4095) / 4096);
+        spread_count_kernel<<<dim3(std::max(gx, 1), B), 256, 0, (hipStream_t)st>>>(p, per_window, rows, e[i].ld, e[i].col0, e[i].ncols, ws.r(e[i].rec),
+                                                                                  e[i].rec2 >= 0 ? ws.r(e[i].rec2) : nullptr, counts + (size_t)i * B * 3);
+        EV2H_CHECK_LAUNCH();
+    }
+    return EV2H_OK;
+}
 
 extern "C" size_t ev2h_workspace_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
@@ -612,6 +717,7 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     }
     const ev2h_mano_consts* mano[2] = {mano_left, mano_right};
     SideCtx* side = side_ctx();
+    if (g_side_disabled) side = nullptr;
     bool forked = false;
     const int rc = forward_body(w, mano, xyz_cm, B, C, N, mhlnes, fps_init, out, ws, st, side, &forked);
     if (forked) {

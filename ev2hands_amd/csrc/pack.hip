@@ -469,6 +469,19 @@ std::vector<uint8_t> gemm_image(const double* W, int N, int K, int ns, int rows,
 
 // ---------------------------------------------------------------------------------------------------- the packed object
 struct Blob { std::string name; int dtype; int rows, cols; size_t off, bytes; };
+// F16X2: how a matrix sits inside its ONE power-of-two scale: weights with 0 < |w / u| < 2^-3 (more than ~2^17 below the matrix
+// maximum: low plane subnormal) and < 2^-14 (high plane subnormal too)
+struct WSpread { std::string name; uint64_t nonzero = 0, low = 0, high = 0; };
+
+WSpread weight_spread(const std::string& name, const double* W, size_t count, double u) {
+    WSpread r;
+    r.name = name;
+    for (size_t i = 0; i < count; ++i) {
+        const double a = std::fabs(W[i] / u);
+        if (a > 0) { ++r.nonzero; r.low += a < 0.125; r.high += a < 6.103515625e-05; }
+    }
+    return r;
+}
 
 }  // namespace
 
@@ -479,6 +492,7 @@ struct ev2h_packed {
     void* dev = nullptr;
     size_t dev_bytes = 0;
     Equalization eq;
+    std::vector<WSpread> wspread;
 };
 
 namespace {
@@ -539,6 +553,7 @@ struct Builder {
         if (ps) vec(&d.post_scale, name + ".ps", *ps);
         if (pt) vec(&d.post_shift, name + ".pt", *pt);
         d.O = O; d.K = K ? K : ldw; d.ldw = ldw;
+        if (ns == 2) P.wspread.push_back(weight_spread(name, W.data(), W.size(), plane_unscale(W.data(), W.size(), ns)));
         if (ns && O >= 96) {             // all but the tiny heads: pre-split W images, streamed by LDS-DMA
             dev_bytes(&d.Ws, name + ".Ws", gemm_image(Wp.data(), O, ldw, ns, GEMM_W_TILE_ROWS, &d.w_unscale));
             d.ws_tile_rows = GEMM_W_TILE_ROWS;
@@ -569,6 +584,10 @@ struct Builder {
     void chain_images(ev2h_sa_branch& br, const std::string& n, const double* W2, const double* W3, int C1, int C2, int C3) {
         SaImages im = sa_images(W2, W3, C1, C2, C3, ns);
         br.w2_unscale = im.u2; br.w3_unscale = im.u3;
+        if (ns == 2) {
+            P.wspread.push_back(weight_spread(n + ".W2", W2, (size_t)C2 * C1, im.u2));
+            P.wspread.push_back(weight_spread(n + ".W3", W3, (size_t)C3 * C2, im.u3));
+        }
         dev_bytes(&br.W2s, n + ".W2s", im.i2);
         dev_bytes(&br.W3s, n + ".W3s", im.i3);
     }
@@ -609,6 +628,7 @@ struct Builder {
         vec(&m.b1, prefix + ".b1", b1);
         if (ns && kf >= 32) {            // enc.sa2 (K = 320): plane images, the fast GEMM kernel
             dev_bytes(&m.W1fs, prefix + ".W1fs", gemm_image(W1f.data(), c1sum, kf, ns, GEMM_W_TILE_ROWS, &m.w1f_unscale));
+            if (ns == 2) P.wspread.push_back(weight_spread(prefix + ".W1f", W1f.data(), W1f.size(), m.w1f_unscale));
         } else {
             m.w1f_unscale = (float)plane_unscale(W1f.data(), W1f.size(), ns);      // K = 8 tables run as fp32 fma chains (table_k8_kernel)
         }
@@ -635,6 +655,7 @@ struct Builder {
         dev(&m.W1f, n + ".W1f", L0.W.data(), L0.O, L0.I);
         vec(&m.b1, n + ".b1", L0.b);
         dev_bytes(&m.W1fs, n + ".W1fs", gemm_image(L0.W.data(), L0.O, L0.I, ns, GEMM_W_TILE_ROWS, &m.w1f_unscale));
+        if (ns == 2) P.wspread.push_back(weight_spread(n + ".W1f", L0.W.data(), L0.W.size(), m.w1f_unscale));
         m.w1f_norm = bound(max_row_l1(L0.W.data(), L0.O, L0.I, L0.I));
         m.b1_max = bound(max_abs(L0.b));
     }
@@ -845,6 +866,16 @@ extern "C" int ev2h_packed_equalization(const ev2h_packed* p, int i, const char*
     if (name) *name = p->eq[i].first.c_str();
     if (e) *e = p->eq[i].second.data();
     if (n) *n = (int)p->eq[i].second.size();
+    return EV2H_OK;
+}
+
+extern "C" int ev2h_packed_weight_spread_count(const ev2h_packed* p) { return p ? (int)p->wspread.size() : 0; }
+
+extern "C" int ev2h_packed_weight_spread(const ev2h_packed* p, int i, const char** name, uint64_t counts[3]) {
+    EV2H_CHECK_ARG(p && counts && i >= 0 && i < (int)p->wspread.size());
+    const WSpread& w = p->wspread[i];
+    if (name) *name = w.name.c_str();
+    counts[0] = w.nonzero; counts[1] = w.low; counts[2] = w.high;
     return EV2H_OK;
 }
 

@@ -103,12 +103,18 @@ class GatherBuffer:
     def __init__(self, N: int, global_batch: int, device, group=None):
         self.group, self.N = group, N
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if global_batch < self.world:
+            # a rank without a window would skip its forward (ev2h_forward needs B > 0) while the others wait in the collective:
+            # refused here, on EVERY rank (the sizes are a pure function of global_batch and the world size)
+            raise ValueError(f"global batch {global_batch} < world size {self.world}: every rank needs at least one window")
+        self.generation = 0          # bumped whenever rows() hands the buffer to a new forward (GatherPipeline.Pending checks it)
         self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
         self.big = max(self.sizes)
         self.full = torch.zeros(self.world * self.big, packed_width(N), dtype=torch.float32, device=device)
 
     def rows(self) -> torch.Tensor:
         lo = self.rank * self.big
+        self.generation += 1
         return self.full[lo:lo + self.sizes[self.rank]]
 
     def gather(self) -> dict:
@@ -137,6 +143,7 @@ class GatherPipeline:
     class Pending:
         def __init__(self, buf, work):
             self.buf, self.work, self._out = buf, work, None
+            self.generation = buf.generation                # the forward whose predictions this gather carries
 
         def wait(self):
             if self.work is not None:
@@ -144,6 +151,9 @@ class GatherPipeline:
                 self.work = None
 
         def result(self) -> dict:
+            if self.buf.generation != self.generation:
+                raise RuntimeError("this gather's buffer was handed to a later forward (GatherPipeline.rows()): its predictions are "
+                                   "overwritten -- ask for result() before the buffer comes round again, or raise `depth`")
             self.wait()
             if self._out is None:
                 b = self.buf

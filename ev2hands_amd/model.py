@@ -96,7 +96,10 @@ class TEHNet(nn.Module):
         # arithmetic of the matrix contractions: "f16x2" (default: fp32-class two-plane fp16 split with exact
         # per-window range scaling, any checkpoint / input magnitude), "bf16x3" (fp32-class three-plane bf16 split), "f32"
         # (exact fp32 MFMA), "bf16" (reduced precision)
+        # "auto": the first forward (and the first after the weights change) runs verify_precision on ITS OWN batch and keeps "f16x2"
+        # only if every output agrees with "bf16x3" to AUTO_TOLERANCE and the segmentation argmax is identical; else "bf16x3"
         self.precision = os.getenv("EV2H_PRECISION", "f16x2")
+        self._auto = None             # (pack key of the weights, chosen mode, report) of the last "auto" decision
         # exact power-of-two equalisation of the hidden channels when the checkpoint is packed (pack.py: equalize_channels): the
         # fp32 function is unchanged bit for bit, the 16-bit planes see well-conditioned operands whatever the BatchNorm scales are
         self.equalize = True
@@ -115,6 +118,13 @@ class TEHNet(nn.Module):
         # (walking the module tree costs ~2 ms per call -- more than a B = 1 forward; the tensor list is cached and dropped
         # whenever nn.Module machinery may have replaced tensor objects: _apply (.to / .cuda / .float) and load_state_dict)
         ts = self._key_tensors
+        self._key_calls = getattr(self, "_key_calls", 0) + 1
+        if ts is not None and self._key_calls % 64 == 0:
+            # tensors can also be replaced behind nn.Module's back (net.sa1.conv_blocks[0][0].weight = nn.Parameter(..), a
+            # submodule's load_state_dict(assign=True), parametrize / prune): re-walk the tree now and then and compare identities
+            fresh = list(self.parameters()) + list(self.buffers())
+            if len(fresh) != len(ts) or any(a is not b for a, b in zip(fresh, ts)):
+                ts = None
         if ts is None:
             ts = self._key_tensors = list(self.parameters()) + list(self.buffers())
             self._key_gen += 1
@@ -128,7 +138,7 @@ class TEHNet(nn.Module):
     def _version_key(self):
         """the cheap part of _pack_key (in-place modifications, module-level replacement): what a captured graph re-checks per replay"""
         ts = self._key_list()
-        return (self._key_gen, [t._version for t in ts])
+        return (self._key_gen, [t._version for t in ts], [t.data_ptr() for t in ts])     # data_ptr: `p.data = new_tensor` keeps _version
 
     def _apply(self, fn, *args, **kwargs):
         self._key_tensors = None
@@ -138,10 +148,25 @@ class TEHNet(nn.Module):
         self._key_tensors = None
         return super().load_state_dict(*args, **kwargs)
 
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Parameter, nn.Module)):
+            self.__dict__["_key_tensors"] = None
+        super().__setattr__(name, value)
+
+    AUTO_TOLERANCE = 1e-5
+
+    def effective_precision(self) -> str:
+        """the arithmetic mode the next forward runs in ("auto" resolved; before its first decision: "f16x2")"""
+        if self.precision != "auto":
+            return self.precision
+        return self._auto[1] if self._auto is not None else "f16x2"
+
     def packed(self, device) -> PackedWeights:
-        key = (str(device), self.precision, self.equalize, self._pack_key())
+        prec = self.effective_precision()
+        key = (str(device), prec, self.equalize, self._pack_key())
         if self._packed is None or self._packed_key != key:
-            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, self.precision, equalize=self.equalize)
+            self._packed = None                   # (free the old device image first)
+            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, prec, equalize=self.equalize)
             self._packed_key = key
         return self._packed
 
@@ -241,6 +266,82 @@ class TEHNet(nn.Module):
         self._last_ws = ws
         return res
 
+    # -- the f16x2 guard: what the DATA does to the split arithmetic ---------------------------------
+    def range_report(self) -> dict:
+        """After a forward in "f16x2": for every contraction operand that is materialised in the workspace (ev2h_range_report),
+        {"nonzero", "below_2^-17", "below_2^-28"}: int64 [B] counts per window of the values that sit more than ~2^17 / ~2^28 below
+        the window's maximum -- the ones the two-plane fp16 split resolves less finely than fp32 -- plus "worst_fraction" =
+        max over the windows of below_2^-17 / nonzero."""
+        B, N = self._last_shape
+        L = _lib.lib()
+        names = (C.c_char_p * 64)()
+        n = L.ev2h_range_report_entries(names, 64)
+        ws = self._last_ws
+        counts = torch.zeros(n, B, 3, dtype=torch.int32, device=ws.device)
+        with torch.cuda.device(ws.device):
+            _lib.check(L.ev2h_range_report(ws.data_ptr(), B, N, counts.data_ptr(), _lib.stream_handle()), "ev2h_range_report")
+        c = counts.cpu().to(torch.int64)
+        out = {}
+        for i in range(n):
+            nz, lo, hi = c[i, :, 0], c[i, :, 1], c[i, :, 2]
+            out[names[i].decode()] = {"nonzero": nz, "below_2^-17": lo, "below_2^-28": hi,
+                                      "worst_fraction": float((lo.double() / nz.clamp(min=1).double()).max())}
+        return out
+
+    def verify_precision(self, xyz, mano_hands, fps_init=None, reference: str = "bf16x3") -> dict:
+        """Run THIS batch in "f16x2" and in `reference` ("bf16x3": three exact bf16 planes, 8 exponent bits, no range assumption;
+        or "f32") with the same FPS start indices and compare: {"max_rel": worst per-tensor relative difference
+        (max|a - b| / max|b|) over class_logits and both hands' parameters / vertices / joints, "per_output": ..., "argmax_agreement":
+        fraction of points with the same segmentation class, "range": range_report() of the f16x2 run, "weights": packed-weight
+        spread, "ok": max_rel <= AUTO_TOLERANCE and identical argmax}.  Costs two forwards and two packs; the network's precision
+        setting is restored."""
+        self._check_input(xyz)
+        B, _, N = xyz.shape
+        inits = fps_init if fps_init is not None else (self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N))
+        keep = self.precision
+        outs = {}
+        try:
+            for prec in ("f16x2", reference):
+                self.precision = prec
+                self.fps_init = inits
+                x = xyz.clone() if self.mhlnes else xyz
+                with torch.no_grad():
+                    o = self.forward(x, mano_hands)
+                outs[prec] = {"class_logits": o["class_logits"].clone(),
+                              **{f"{s}.{k}": o[s][k].clone() for s in ("left", "right") for k in ("global_orient", "hand_pose", "betas", "transl", "vertices", "j3d")}}
+                if prec == "f16x2":
+                    rng = self.range_report()
+                    wsp = self._packed.weight_spread()
+        finally:
+            self.precision = keep
+            self.fps_init = None
+        a, b = outs["f16x2"], outs[reference]
+        per = {k: float((a[k] - b[k]).abs().max() / b[k].abs().max().clamp(min=1e-30)) for k in a}
+        agree = float((a["class_logits"].argmax(1) == b["class_logits"].argmax(1)).float().mean())
+        nzw = sum(v[0] for v in wsp.values())
+        rep = {"max_rel": max(per.values()), "per_output": per, "argmax_agreement": agree, "reference": reference, "range": rng,
+               "range_worst": max(rng.items(), key=lambda kv: kv[1]["worst_fraction"])[0] if rng else None,
+               "weights": {"nonzero": nzw, "below_2^-17": sum(v[1] for v in wsp.values())}}
+        rep["ok"] = bool(rep["max_rel"] <= self.AUTO_TOLERANCE and agree == 1.0)
+        return rep
+
+    def _auto_decide(self, xyz, mano_hands, inits):
+        key = (str(xyz.device), self.equalize, self._pack_key())
+        if self._auto is not None and self._auto[0] == key:
+            return
+        self._auto = None
+        self.precision = "f16x2"
+        try:
+            rep = self.verify_precision(xyz, mano_hands, fps_init=inits)
+        finally:
+            self.precision = "auto"
+        self._auto = (key, "f16x2" if rep["ok"] else "bf16x3", rep)
+
+    @property
+    def auto_report(self):
+        """verify_precision's report behind the current "auto" choice (None before the first forward)"""
+        return None if self._auto is None else self._auto[2]
+
     def forward(self, xyz, mano_hands, rows=None):
         """TEHNet.py:168-197.  rows (extension, optional): float32 [B, >= 4N + 2 * 2419] matrix that receives each window's
         predictions as one row ([4N logits | left 22 params, 778x3 vertices, 21x3 joints | right ...], ev2hands_amd/dist.py);
@@ -251,6 +352,8 @@ class TEHNet(nn.Module):
         x = xyz if self.mhlnes else xyz.contiguous()
         inits = self.fps_init if self.fps_init is not None else self.draw_fps_init(B, N)
         self.fps_init = None
+        if self.precision == "auto":
+            self._auto_decide(xyz, mano_hands, inits)
         init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
         res = self._enqueue(x, init_dev, mano_hands, rows=rows)
         for side in ("left", "right"):
@@ -265,7 +368,9 @@ class TEHNet(nn.Module):
         if hit is None:
             if len(self._faces_cache) > 8:
                 self._faces_cache.clear()
-            hit = self._faces_cache[key] = (np.tile(hand.faces, (B, 1, 1)), hand, hand.faces)
+            tiled = np.tile(hand.faces, (B, 1, 1))
+            tiled.flags.writeable = False        # shared between forwards (the reference returns a fresh array each time): editing it in place must raise
+            hit = self._faces_cache[key] = (tiled, hand, hand.faces)
         return hit[0]
 
     def capture(self, xyz, mano_hands, fps_init=None) -> "CapturedForward":
@@ -306,8 +411,10 @@ class CapturedForward:
         # workspace is re-allocated by a later, larger eager forward, and the packed weights are dropped when the parameters or
         # the precision change (a replay would then read and write freed memory).
         self._ws = torch.empty(_lib.lib().ev2h_workspace_bytes(B, N), dtype=torch.uint8, device=device)
+        if net.precision == "auto":
+            net._auto_decide(self.x, mano_hands, [t.cpu() for t in self.init])
         self._pw = net.packed(device)
-        self._key = (net.precision, net.equalize, net._version_key())
+        self._key = (net.effective_precision(), net.equalize, net._version_key())
         for s in ("left", "right"):
             mano_hands[s].consts()
         self._mano_keep = {s: (mano_hands[s]._keep, mano_hands[s].shapedirs._version) for s in ("left", "right")}    # MANO constant tensors
@@ -319,6 +426,7 @@ class CapturedForward:
                 self.out = net._enqueue(self.x, self.init, mano_hands, ws=self._ws)
         self.faces = {s: np.tile(mano_hands[s].faces, (B, 1, 1)) for s in ("left", "right")}
         for s in ("left", "right"):
+            self.faces[s].flags.writeable = False             # shared by every replay
             self.out[s]["faces"] = self.faces[s]
         if net.mhlnes:
             self.x.copy_(xyz)                                 # MHLNES=1 overwrote channel 2 during warm-up and capture
@@ -326,7 +434,7 @@ class CapturedForward:
     def replay(self, xyz=None, fps_init=None) -> dict:
         """Run the captured forward (optionally on new inputs of the captured shape).  The returned tensors are the graph's static
         outputs: they are overwritten by the next replay."""
-        if (self.net.precision, self.net.equalize, self.net._version_key()) != self._key:
+        if (self.net.effective_precision(), self.net.equalize, self.net._version_key()) != self._key:
             raise RuntimeError("the network's parameters, device or precision changed since this forward was captured: the graph "
                                "holds the old packed weights -- capture again")
         if any(self.hands[s].shapedirs._version != self._mano_keep[s][1] for s in ("left", "right")):

@@ -106,6 +106,15 @@ class PackedWeights:
             self._eq = out
         return self._eq
 
+    def weight_spread(self) -> dict:
+        """f16x2 only: matrix -> (non-zero weights, weights more than ~2^17 below the matrix maximum, more than ~2^28 below)"""
+        L, out = _lib.lib(), {}
+        name, c = C.c_char_p(), (C.c_uint64 * 3)()
+        for i in range(L.ev2h_packed_weight_spread_count(self._handle)):
+            _lib.check(L.ev2h_packed_weight_spread(self._handle, i, C.byref(name), c))
+            out[name.value.decode()] = tuple(int(v) for v in c)
+        return out
+
     def nbytes(self) -> int:
         return int(_lib.lib().ev2h_packed_bytes(self._handle))
 

@@ -76,6 +76,11 @@ const char* ev2h_last_error(void);
  * two-stream overlaps (~5 % of a B = 256 step).  (Raising GPU_MAX_HW_QUEUES is no substitute: 8 queues cured the late-creation case
  * but cost 10 % when the side stream was created first.) */
 int ev2h_init(void);
+/* Per host thread: enabled = 0 makes ev2h_forward run every kernel on the caller's stream (no fork onto the library's side stream);
+ * 1 (default) restores the two-stream schedule.  Results are bit-identical; returns the previous setting.  A host uses it to MEASURE
+ * what the overlaps buy in its own process (bench.py's `two_stream_gain`): a gain of ~1.00 where ~1.05 is expected means the side
+ * stream shares a hardware queue with the caller's stream (see ev2h_init). */
+int ev2h_set_side_stream(int enabled);
 /* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp, tensor_desc]. */
 void ev2h_struct_sizes(size_t out[8]);
 
@@ -451,6 +456,14 @@ int ev2h_packed_tensor(const ev2h_packed* p, int i, const char** name, int* rows
  * e [n] powers of two, the accumulated factor channel c was multiplied by. */
 int ev2h_packed_equalization_count(const ev2h_packed* p);
 int ev2h_packed_equalization(const ev2h_packed* p, int i, const char** name, const double** e, int* n);
+/* F16X2 only (0 entries otherwise): how the i-th weight matrix sits inside its one power-of-two scale -- counts = {non-zero weights,
+ * weights with 0 < |w / u| < 2^-3 (more than ~2^17 below the matrix maximum: their low fp16 plane is subnormal), weights below 2^-14}.
+ * The weight side of the accuracy contract at the top of this file.  Measured on synthetic checkpoints (4.6 M weights): with
+ * EV2H_PACK_EQUALIZE ~150 weights below 2^-17 for a plain checkpoint and for one whose channels were rescaled to 2^32 apart; 1 % for
+ * log-normal heavy-tailed weights (tiny weights next to outliers 400 x the median: they do not matter); WITHOUT equalisation 66 % of
+ * the weights of the rescaled checkpoint (the 0.23 relative error quoted above). */
+int ev2h_packed_weight_spread_count(const ev2h_packed* p);
+int ev2h_packed_weight_spread(const ev2h_packed* p, int i, const char** name, uint64_t counts[3]);
 /* The image builders on their own (operator-level callers of ev2h_sa_mlp_max / ev2h_fp_mlp / ev2h_gemm): W2 [C2][C1], W3 [C3][C2],
  * W [N][K] row-major float64 on the HOST; img* = caller's HOST buffers of ev2h_pack_*_bytes bytes; u* = the power-of-two factor
  * the planes were divided by (w2_unscale / w3_unscale / w_unscale).  planes: 1 BF16, 2 F16X2, 3 BF16X3. */
@@ -491,6 +504,20 @@ size_t ev2h_workspace_bytes(int B, int N);
 int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_left, const ev2h_mano_consts* mano_right,
                  float* xyz_cm, int B, int C, int N, int mhlnes, const int64_t* fps_init, const ev2h_outputs* out,
                  void* workspace, size_t workspace_bytes, ev2h_stream_t stream);
+
+/* F16X2 spread report (the activation side of the accuracy contract at the top of this file).  After an ev2h_forward with F16X2
+ * weights, for every operand tensor of a contraction that is materialised in `workspace` (names: ev2h_range_report_entries; the
+ * hidden layers inside the fused kernels never reach memory and are not listed) and every window b:
+ *   counts[(i * B + b) * 3 + 0] = non-zero values,
+ *   counts[(i * B + b) * 3 + 1] = values with 0 < |v| * s < 2^-3  -- more than ~2^17 below the window's maximum: their low fp16 plane is
+ *                                 subnormal, fewer than 22 bits survive the split (absolute error <= 2^-39 of the maximum),
+ *   counts[(i * B + b) * 3 + 2] = values with 0 < |v| * s < 2^-14 -- more than ~2^28 below the maximum: the high plane is subnormal too,
+ * with s the power of two the consumer scales the window by (from the tensor's range record(s)).  counts: DEVICE uint32
+ * [entries][B][3], zeroed here.  A separate pass over the workspace of the LAST forward (same B, N): nothing is added to the
+ * forward itself.  Large fractions in column 1 say that this input / checkpoint leans on values the F16X2 split resolves less
+ * finely than fp32 does -- compare with BF16X3 (TEHNet.verify_precision does) before trusting the mode. */
+int ev2h_range_report_entries(const char** names, int max_names);     /* returns the number of entries */
+int ev2h_range_report(void* workspace, int B, int N, uint32_t* counts, ev2h_stream_t stream);
 
 /* Measurement hook (bench.py): record caller-owned hipEvent_t pairs around ONE launch site of
  * ev2h_forward, on the forward's stream.  tag = "<module>.<branch>" with module in {sa1, sa2, manoL,

@@ -218,7 +218,7 @@ def tehnet_forward(sd, xyz_in, mano_hands, fps_init=None, n_pose=6, training=Fal
     xyz0 = xyz_in[:, :3, :]
     if mhlnes:
         xyz0[:, -1, :] = xyz_in[:, 3:, :].mean(1)        # in place, like TEHNet.py:176-177
-    l1_xyz, l1 = sa_msg(sd, "sa1", xyz0, feat0, 512, [0.1, 0.2, 0.4], [32, 64, 128], fi[0], trace)      # TEHNet.py:128
+    l1_xyz, l1 = sa_msg(sd, "sa1", xyz0, feat0, 512, [0.1, 0.2, 0.4], [32, 64, 128], fi[0], trace)      # TEHNet.py:127
     l2_xyz, l2 = sa_msg(sd, "sa2", l1_xyz, l1, 128, [0.4, 0.8], [64, 128], fi[1], trace)               # TEHNet.py:128
     l3_xyz, l3 = sa_group_all(sd, "sa3", l2_xyz, l2)
     if trace is not None:

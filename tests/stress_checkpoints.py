@@ -158,3 +158,34 @@ def add_outlier_points(xyz: torch.Tensor, value: float, channel: int = 3, per_wi
         idx = hash_randint(f"outlier/{b}", 0, N, (per_window,), seed)
         out[b, channel, torch.from_numpy(idx)] = float(value)
     return out
+
+
+def coherent_channels(sd: dict, fraction: float = 0.25, seed: int = 0, probe=None) -> "OrderedDict":
+    """Checkpoint whose hidden activations are large in a way NO WEIGHT NORM shows (what a data-free equalisation rule cannot see):
+    in every convolution / linear that reads a hidden tensor, a `fraction` of the output channels get the ABSOLUTE VALUES of their
+    weights on the hidden input columns (raw-input columns keep their signs).  Hidden inputs are post-ReLU, i.e. non-negative and
+    positively correlated through their common mean, so such a row adds its inputs coherently -- a pre-activation of about
+    |w|_1 mean(h) instead of |w|_2 std(h), a factor ~sqrt(fan-in) -- at EXACTLY the same row norm and column norms; the eval
+    BatchNorm keeps its (now stale) running statistics and does not remove that mean; and because coherent rows also read the
+    previous layer's coherent channels, the effect compounds through the three layers of every MLP.  The result: inside one
+    tensor some channels are orders of magnitude above the others although the packer's row / column norms are level.
+    This is a DIFFERENT network (the oracle evaluates the same checkpoint), not a re-parameterisation.
+    probe: optional callable(state_dict) -> dict name -> float, the magnitude of the network outputs; the last layers (classifier.4,
+    *_mano_regressor.mano_regressor.4) are then scaled so that the outputs are O(1) again (hand poses of thousands of radians
+    would make every arithmetic mode miss the bar through MANO's trigonometry, as the 1e8-event hot pixel does)."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for bn, nch, consumers in channel_wiring():
+        for key, off in consumers:
+            w = out[key].double().numpy().copy()
+            rows = hash_uniform("coherent/" + key, (w.shape[0],), seed) < fraction
+            blk = w[:, off:off + nch]
+            blk[rows] = np.abs(blk[rows])
+            w[:, off:off + nch] = blk
+            out[key] = torch.from_numpy(w.astype(np.float32))
+    if probe is not None:
+        mag = probe(out)
+        for key, m in mag.items():
+            if m > 0:
+                out[key + ".weight"] = out[key + ".weight"] / float(m)
+                out[key + ".bias"] = out[key + ".bias"] / float(m)
+    return out

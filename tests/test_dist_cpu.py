@@ -55,6 +55,14 @@ def _worker_inplace(rank, world, port, gB, N, q, steps=2):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = evdist.shard_range(gB, rank, world)
+    if gB < world:                                         # a rank without a window would leave the others in the collective:
+        try:                                               # refused on EVERY rank, before any collective
+            evdist.GatherBuffer(N, gB, "cpu")
+            q.put((rank, False))
+        except ValueError as e:
+            q.put((rank, "every rank needs at least one window" in str(e)))
+        dist.destroy_process_group()
+        return
     buf = evdist.GatherBuffer(N, gB, "cpu")
     ok = buf.rows().shape == (hi - lo, evdist.packed_width(N)) and (hi == lo or buf.rows().data_ptr() == buf.full[rank * buf.big:].data_ptr())
     for step in range(steps):
@@ -89,6 +97,15 @@ def _worker_pipeline(rank, world, port, gB, N, q, steps=5):
     for st, h in handles:
         full, want = h.result(), _fake_outputs(100 * st, gB + 100 * st, N)
         ok = ok and torch.equal(full["class_logits"], want["class_logits"]) and torch.equal(full["left"]["j3d"], want["left"]["j3d"])
+    # a result asked for AFTER its buffer was handed to a later forward is refused instead of returning overwritten rows
+    stale = pipe.submit()
+    pipe.rows(); pipe.submit(); pipe.rows()                # depth 2: the second rows() hands stale's buffer out again
+    try:
+        stale.result()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "handed to a later forward" in str(e)
+    pipe.drain()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -1,0 +1,181 @@
+"""GPU: the activation-based guard of the default f16x2 arithmetic (VERDICT r3 "next" #2): the spread report of the materialised
+operand tensors (ev2h_range_report), TEHNet.verify_precision (f16x2 against bf16x3 on the caller's own batch), precision="auto",
+and a stress checkpoint whose hidden activations are large in a way no weight norm shows (coherent rows on correlated,
+non-negative inputs with stale BatchNorm statistics).  The fp32 semantics being guarded: pointnet2_utils.py:253-256,312-314,
+TEHNet.py:135-166 (every layer is fp32 in the reference)."""
+import numpy as np
+import pytest
+import torch
+
+import stress_checkpoints as sc
+from ev2hands_amd import synth
+from test_gpu_forward import _need_gpu, check_against, make_net, rel, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _scale_of(amax: torch.Tensor) -> torch.Tensor:
+    """planes.hpp: f16x2_scale for a float32 tensor of maxima"""
+    E = (amax.view(torch.int32) >> 23) & 0xFF
+    sb = torch.where(E == 255, torch.full_like(E, 127), torch.clamp(268 - E, max=200))
+    return (sb << 23).view(torch.float32)
+
+
+def test_range_report_equals_a_host_count():
+    _need_gpu()
+    C, N, B, seed = 5, 256, 3, 2
+    net, sd, assets = make_net(C, seed, precision="f16x2")
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    xyz = sc.add_outlier_points(xyz, 3.0e6, channel=3, per_window=1, seed=seed)      # one window-wide maximum far above the rest
+    net.net.fps_init = inits
+    with torch.no_grad():
+        net(xyz.cuda())
+    rep = net.net.range_report()
+    assert {"feat", "l1", "l1cat", "l2", "l0", "hfL", "m1R", "fc1L", "l3"} <= set(rep)
+    dbg = net.net.debug_buffer
+    cases = {"feat": (dbg("feat8").view(B, N, 8), ["feat"]), "l0": (dbg("l0").view(B, N, 256), ["l0"]),
+             "l1cat": (dbg("l1cat").view(B, 512, 576), ["l1a", "l1b"]), "l2": (dbg("l2buf").view(B, 128, 520)[:, :, :515], ["l2", "feat"]),
+             "sa3h2": (dbg("sa3h2").view(B, 128, 512), ["sa3h2"]), "fc1R": (dbg("fc1R").view(B, 1, 1024), ["fc1R"])}
+    for name, (buf, recs) in cases.items():
+        amax = torch.stack([dbg("rng." + r, torch.int32).view(torch.float32) for r in recs]).amax(0)
+        v = buf.abs().reshape(B, -1) * _scale_of(amax).view(B, 1)
+        want = torch.stack([(v > 0).sum(1), ((v > 0) & (v < 0.125)).sum(1), ((v > 0) & (v < 2.0 ** -14)).sum(1)], 1).cpu()
+        got = torch.stack([rep[name]["nonzero"], rep[name]["below_2^-17"], rep[name]["below_2^-28"]], 1)
+        assert torch.equal(got, want), (name, got, want)
+    # the hot pixel pushes every other input value more than 2^17 below the window's maximum: the report says so
+    assert rep["feat"]["worst_fraction"] > 0.5
+    # ... while the same cloud without it sits inside the range (coordinates in [-1, 1], counts 0..7)
+    net.net.fps_init = inits
+    with torch.no_grad():
+        net(synth.synth_cloud("E", B, C, N, seed).cuda())
+    assert net.net.range_report()["feat"]["worst_fraction"] < 0.01
+
+
+def test_verify_precision_on_a_plain_checkpoint():
+    _need_gpu()
+    C, N, B, seed = 4, 512, 2, 6
+    net, sd, assets = make_net(C, seed, precision="f16x2")
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    rep = net.net.verify_precision(xyz.cuda(), net.hands, fps_init=inits)
+    print({k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in rep.items() if k not in ("range", "per_output")}, "worst tensor", rep["range_worst"],
+          f'{rep["range"][rep["range_worst"]]["worst_fraction"]:.2e}')
+    assert rep["ok"] and rep["max_rel"] < 1e-5 and rep["argmax_agreement"] == 1.0
+    assert rep["weights"]["below_2^-17"] < 1e-3 * rep["weights"]["nonzero"]
+    assert net.net.precision == "f16x2" and net.net.fps_init is None                 # settings restored
+    # against exact fp32 as the reference mode
+    rep32 = net.net.verify_precision(xyz.cuda(), net.hands, fps_init=inits, reference="f32")
+    assert rep32["ok"]
+
+
+@pytest.mark.parametrize("equalize", [True, False])
+def test_auto_mode_keeps_f16x2_only_where_it_is_fp32_class(equalize):
+    """A checkpoint with hidden channels 2^24 apart: with the packer's equalisation f16x2 is fp32-class and "auto" keeps it; packed
+    WITHOUT equalisation (explicit opt-out) the same kernels are off by 0.2 -- "auto" measures that on the caller's own batch,
+    falls back to bf16x3 and the forward holds the parity bar against the oracle."""
+    _need_gpu()
+    C, N, B, seed = 5, 256, 2, 3
+    net, sd0, assets = make_net(C, seed, precision="auto")
+    sd = sc.rescale_channels(sd0, 12, seed)
+    net.load_state_dict(sd, strict=True)
+    net.net.equalize = equalize
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    assert net.net.auto_report is None
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    rep = net.net.auto_report
+    print(f"equalize={equalize}: auto chose {net.net.effective_precision()}, f16x2 vs bf16x3 max rel {rep['max_rel']:.2e}, argmax agreement "
+          f"{rep['argmax_agreement']:.4f}, weights below 2^-17: {rep['weights']['below_2^-17']} of {rep['weights']['nonzero']}, worst tensor "
+          f"{rep['range_worst']} {rep['range'][rep['range_worst']]['worst_fraction']:.2e}")
+    if equalize:
+        assert net.net.effective_precision() == "f16x2" and rep["ok"]
+    else:
+        assert net.net.effective_precision() == "bf16x3" and not rep["ok"] and rep["max_rel"] > 1e-4
+        assert rep["weights"]["below_2^-17"] > 0.05 * rep["weights"]["nonzero"]      # the weight-side report shows why
+    check_against(out, net, ref, trace, B, N)
+    # the decision is kept while the weights stay, and redone when they change
+    key = net.net._auto[0]
+    net.net.fps_init = inits
+    with torch.no_grad():
+        net(xyz.cuda())
+    assert net.net._auto[0] == key
+    net.load_state_dict(sd0, strict=True)
+    net.net.fps_init = inits
+    with torch.no_grad():
+        net(xyz.cuda())
+    assert net.net._auto[0] != key and net.net.effective_precision() == "f16x2"
+
+
+def test_unequalised_f16x2_weights_are_refused_without_the_opt_out():
+    _need_gpu()
+    import ctypes as C
+    from ev2hands_amd import _lib, pack
+    Cc, N, B, seed = 4, 256, 1, 1
+    net, sd, assets = make_net(Cc, seed, precision="f16x2")
+    L = _lib.lib()
+    descs, keep = pack.tensor_descs(sd)
+    h = C.c_void_p()
+    _lib.check(L.ev2h_pack_weights(descs, len(descs), Cc, _lib.PREC["f16x2"], 0, C.byref(h)), "pack")     # neither equalised nor opted out
+    try:
+        w = _lib.Weights.from_address(L.ev2h_packed_weights(h))
+        assert w.flags == 0
+        x = synth.synth_cloud("E", B, Cc, N, seed).cuda()
+        init = torch.stack(synth.fps_inits(B, N, seed)).cuda()
+        out = _lib.Outputs()
+        logits, prm = torch.empty(B, 4, N, device="cuda"), [torch.empty(B, 22, device="cuda") for _ in range(2)]
+        out.class_logits = logits.data_ptr()
+        out.params[0], out.params[1] = prm[0].data_ptr(), prm[1].data_ptr()
+        nb = L.ev2h_workspace_bytes(B, N)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        rc = L.ev2h_forward(C.byref(w), None, None, x.data_ptr(), B, Cc, N, 0, init.data_ptr(), C.byref(out), ws.data_ptr(), nb, _lib.stream_handle())
+        assert rc != 0 and b"not channel-equalised" in L.ev2h_last_error()
+    finally:
+        L.ev2h_packed_free(h)
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "f32"])
+def test_coherent_channels_checkpoint(precision):
+    """Hidden activations made large by CORRELATED inputs at unchanged row / column norms (stress_checkpoints.coherent_channels): the
+    packer's weight-norm rule sees nothing, the per-channel maxima inside one tensor are up to 2^17 apart (l3: 2^16.9), and the
+    parity bar still holds in every fp32-class mode; the f16x2 run is also checked by verify_precision."""
+    _need_gpu()
+    from oracle import mano_oracle, tehnet_oracle
+    C, N, B, seed = 5, 256, 2, 4
+    net, sd0, assets = make_net(C, seed, precision=precision)
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    hands = mano_oracle.make_hands(assets["left"], assets["right"])
+
+    def probe(sd):
+        with torch.no_grad():
+            o = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits)
+        m = {"classifier.4": float(o["class_logits"].abs().max())}
+        for s in ("left", "right"):
+            p = torch.cat([o[s][k] for k in ("global_orient", "hand_pose", "betas", "transl")], 1)
+            m[f"{s}_mano_regressor.mano_regressor.4"] = float(p.abs().max()) / 0.5
+        return m
+
+    sd = sc.coherent_channels(sd0, 0.1, 1, probe=probe)
+    net.load_state_dict(sd, strict=True)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    spread = {}
+    for k in ("l1_points", "l2_points", "l3_points", "l0_points"):
+        cm = trace[k].abs().amax((0, 2))
+        cm = cm[cm > 0]
+        spread[k] = float(torch.log2(cm.max() / cm.min()))
+    print("per-channel maxima inside one tensor, log2(max / min):", {k: round(v, 1) for k, v in spread.items()})
+    assert max(spread.values()) > 12                                  # the stress is real ...
+    from ev2hands_amd import pack
+    e = pack.PackedWeights(sd, "cpu", C, "f32").equalization
+    e0 = pack.PackedWeights(sd0, "cpu", C, "f32").equalization
+    assert all(np.abs(np.log2(e[k]) - np.log2(e0[k])).max() <= 1.0 for k in e)      # ... and invisible to the weight-norm rule
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    check_against(out, net, ref, trace, B, N)
+    if precision == "f16x2":
+        rep = net.net.verify_precision(xyz.cuda(), net.hands, fps_init=inits)
+        worst = rep["range_worst"]
+        print(f"verify_precision: max rel {rep['max_rel']:.2e}, argmax agreement {rep['argmax_agreement']:.4f}, worst tensor {worst} "
+              f"{rep['range'][worst]['worst_fraction']:.2e} of its values below 2^-17 of the window maximum")
+        assert rep["ok"]

@@ -141,3 +141,15 @@ def test_single_image_exports_equal_the_restatement():
             a, b = ref_pack.gemm_bf16_w_image(W, ns, rows), pack.gemm_bf16_w_image(W, ns, rows)
             assert a[0].tobytes() == b[0].tobytes() and a[1] == b[1]
             assert ref_pack.plane_unscale(W, ns) == pack.plane_unscale(W, ns)
+
+
+def test_weight_spread_report():
+    """The weight side of the f16x2 accuracy contract (ev2h_packed_weight_spread): equalised checkpoints keep all but a few weights
+    within 2^17 of their matrix maximum; the same rescaled checkpoint without equalisation does not."""
+    sd = sc.rescale_channels(synth.synth_state_dict(4, 3), 16.0, 1)
+    tot = lambda pw: tuple(sum(v[i] for v in pw.weight_spread().values()) for i in range(3))      # noqa: E731
+    nz, lo, hi = tot(pack.PackedWeights(sd, "cpu", 4, "f16x2", equalize=True))
+    assert nz > 4_000_000 and lo < 1e-4 * nz and hi == 0
+    nz, lo, hi = tot(pack.PackedWeights(sd, "cpu", 4, "f16x2", equalize=False))
+    assert lo > 0.5 * nz and hi > 0.3 * nz
+    assert pack.PackedWeights(sd, "cpu", 4, "bf16x3").weight_spread() == {}                      # f16x2 only

@@ -4,7 +4,7 @@
 # Every run is its own process (the switches are read once per process); prints windows/s per run and the per-config medians.
 ROUNDS=${1:-3}; shift
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
-ARGS=${AB_ARGS:-"--steps 100 --warmup 5 --no-legs --no-latency --no-cpu-baseline --no-traffic"}
+ARGS=${AB_ARGS:-"--steps 100 --warmup 5 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck"}
 declare -A vals
 for r in $(seq 1 $ROUNDS); do
   i=0
