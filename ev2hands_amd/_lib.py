@@ -32,7 +32,7 @@ class SaDesc(C.Structure):
                 ("B", ci), ("Npts", ci), ("S", ci), ("K", ci),
                 ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci),
                 ("p1_scale", vp), ("p1_amax", vp), ("w1x_norm", C.c_float), ("dmax", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
-                ("out_amax", vp)]
+                ("out_amax", vp), ("feat", vp), ("ldf", ci), ("W1f", vp), ("ldw1f", ci), ("b1", vp), ("nfeat", ci)]
 
 
 class FpDesc(C.Structure):

@@ -320,9 +320,17 @@ static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, i
     return ev2h_gemm(&g, st);
 }
 
+// BF16 with raw feature rows (kf == 8: enc.sa1, the regressors' sa1): layer 1 runs on the matrix pipe inside the fused kernel straight
+// from the feature rows (ev2h_sa_desc.feat) -- no layer-1 table is computed, written (1.46 GB per 256-window step) or gathered.
+// EV2H_BF16_TABLE=1: A/B switch back to the table.
+static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
+    static const bool table = getenv("EV2H_BF16_TABLE") != nullptr;
+    return precision == EV2H_PREC_BF16 && m.kf == 8 && !table;
+}
+
 static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,
                        const int32_t* cnt, int B, int Npts, const float* P1, float* out, int ldo, ev2h_stream_t st, bool ranges,
-                       const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax) {
+                       const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax, const float* feat = nullptr, int nfeat = 0) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     int coff1 = 0, coff3 = 0;
@@ -334,6 +342,9 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
+        if (feat && bf16_direct_layer1(precision, m)) {
+            d.feat = feat; d.ldf = 8; d.W1f = m.W1f + (size_t)coff1 * m.kf; d.ldw1f = m.kf; d.b1 = m.b1 + coff1; d.nfeat = nfeat;
+        }
         if (ranges) {
             d.p1_scale = p1_scale; d.p1_amax = p1_amax; d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
@@ -353,9 +364,10 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
 
 static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
                      int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st,
-                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax) {
-    RUN(sa_table(precision, m, feat, ldf, B, Npts, P1, st, feat_amax, p1_amax, p1_scale));
-    return sa_branches(precision, tag, m, pts4, ctr4, gidx, cnt, B, Npts, P1, out, ldo, st, feat_amax != nullptr, p1_amax, p1_scale, out_amax);
+                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax, int nfeat = 0) {
+    if (!bf16_direct_layer1(precision, m)) RUN(sa_table(precision, m, feat, ldf, B, Npts, P1, st, feat_amax, p1_amax, p1_scale));
+    return sa_branches(precision, tag, m, pts4, ctr4, gidx, cnt, B, Npts, P1, out, ldo, st, feat_amax != nullptr, p1_amax, p1_scale, out_amax,
+                       ldf == 8 ? feat : nullptr, nfeat);
 }
 
 }  // namespace
@@ -513,7 +525,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[4], 0));
         *forked = true;
     }
-    RUN(sa_table(prec, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
+    if (!bf16_direct_layer1(prec, w->sa1)) RUN(sa_table(prec, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[5], side->stream));
     {
         const int S[3] = {512, 128, 128};
@@ -563,7 +575,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
         RUN(sa_branches(prec, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
-                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A)));
+                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {
@@ -669,7 +681,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
         RUN(sa_module(prec, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh,
-                      ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h)));
+                      ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h), 4));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)sh>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
                                                                                    ws.f(nm[6]), 520, 512);
         EV2H_CHECK_LAUNCH();

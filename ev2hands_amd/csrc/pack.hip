@@ -401,6 +401,16 @@ SaImages sa_images(const double* W2in, const double* W3in, int C1, int C2, int C
     std::vector<float> W2p((size_t)R2 * C1, 0.f);
     for (int r = 0; r < C2; ++r)
         for (int k = 0; k < C1; ++k) W2p[(size_t)r * C1 + k] = (float)(W2in[(size_t)r * C1 + k] / u2);
+    if (g[9]) {      // BF16: k slots in the D-register order of the layer-1 MFMA (ev2h_tile_geometry W2PERM)
+        std::vector<float> q(W2p.size());
+        for (int r = 0; r < R2; ++r)
+            for (int c = 0; c < C1 / 32; ++c)
+                for (int h = 0; h < 2; ++h)
+                    for (int m = 0; m < 2; ++m)
+                        for (int e = 0; e < 8; ++e)
+                            q[(size_t)r * C1 + 32 * c + 16 * h + 8 * m + e] = W2p[(size_t)r * C1 + 32 * c + 16 * m + 4 * h + (e & 3) + 8 * (e >> 2)];
+        W2p.swap(q);
+    }
     std::vector<uint16_t> p2[3];
     split_planes_host(W2p, ns, p2);
     if (left) {

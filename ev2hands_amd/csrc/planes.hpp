@@ -71,6 +71,12 @@ __device__ __forceinline__ void split_planes(float x0, float x1, unsigned (&o)[N
     }
 }
 
+// ReLU of two packed bf16 values in one v_pk_max_i16: a negative float's bf16 pattern is a negative int16 (-0 included)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned v) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0}));
+}
+
 // ---- f16x2 activation range (see the header comment) --------------------------------------------------------------------
 // power of two s such that a * s lies in [2^14, 2^15) for the non-negative float with bit pattern `amax_bits`
 // (clamped to 2^73 for tiny / zero maxima; 1 for inf / NaN: garbage in, garbage out, as in the reference)

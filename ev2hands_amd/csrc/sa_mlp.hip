@@ -262,7 +262,7 @@ int launch_sa(const SaP& p, hipStream_t st) {
 int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
 extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
-    EV2H_CHECK_ARG(d && d->P1 && d->pts4 && d->ctr4 && d->gidx && d->W1x && d->b2 && d->b3 && d->out);
+    EV2H_CHECK_ARG(d && (d->P1 || d->feat) && d->pts4 && d->ctr4 && d->gidx && d->W1x && d->b2 && d->b3 && d->out);
     EV2H_CHECK_ARG(d->B > 0 && d->S > 0 && d->Npts > 0 && d->K >= 32 && (d->K % 32) == 0);
     EV2H_CHECK_ARG((d->ldp % 4) == 0);
     if (d->precision != EV2H_PREC_F32) return ev2h_sa_mlp_max_bf16(d, stream);

@@ -43,6 +43,10 @@ struct SaBP {
     // scaled here by the power of two of p1_amax); ncols = leading columns of the last tile that are written; relu_out = 0 drops
     // the last ReLU; out_cm = optional second copy of the output, channel-major [B][ncols][N]
     int ncols; int relu_out; float* out_cm; size_t out_cm_stride;
+    // BF16 (NS = 1), set abstraction: layer 1 runs on the matrix pipe (see L1M in the kernel).  feat != NULL: the layer-1 table is
+    // not needed at all -- the neighbour's raw feature row feat[b][idx][0..nfeat) (nfeat <= 5, row stride ldf floats) and its
+    // relative xyz are contracted with [W1f | W1x | b1] directly (W1f [C1][ldw1f], b1 [C1]); feat == NULL: P1 is the table.
+    const float* feat; int ldf; const float* W1f; int ldw1f; const float* b1; int nfeat;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -71,7 +75,8 @@ struct SaBCfg {
     // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
     // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
     static constexpr int SB2W = (NS == 2) ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
-    static constexpr int SMALL = C1 * 16 + T2 * 32 * 4 + 16 + SB2W;   // W1x, b2, one int for the workgroup's strip count, scaled b2
+    static constexpr int W1B = (NS == 1) ? C1 * 32 : C1 * 16;        // W1x in fp32 (12 B per channel, padded), or -- BF16 -- the layer-1 A tile [C1][16 k] in bf16
+    static constexpr int SMALL = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
     static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
     static constexpr int CPT = fits(2) ? 2 : 1, UPT = CPT;
@@ -107,8 +112,23 @@ struct SaBCfg {
 //              input row itself.
 template <int C1, int C2, int C3, int NS, bool RES, int MODE = 0>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
+    constexpr int WV = SAB_WAVES;
     constexpr bool ROWS = MODE != 0, DIRECT = MODE == 2;
     static_assert(!(RES && ROWS), "the row-output variants stream their tiles");
+    // BF16, set abstraction: LAYER 1 ON THE MATRIX PIPE.  D1[channel][neighbour] = A1 [32 channels][16 k] x B1 [16 k][32 neighbours]
+    // (+ C = the gathered table row when the features are a table) with the k slots
+    //     0..4  feature f_i (hi plane)      5..7  lo(dx, dy, dz)      8..10  hi(dx, dy, dz)      11  1.0 (x b1)      12..15  lo(f_0..f_3)
+    // (hi = bf16(x), lo = bf16(x - hi): inputs keep 16 bits, the weights are bf16 like everywhere in this mode) -- one MFMA per
+    // 32-channel chunk instead of 3 fma + ReLU + convert per (channel, neighbour) pair (288 -> ~100 VALU instructions per strip),
+    // and with raw feature rows (<= 5 channels: enc.sa1, the regressors' sa1) no layer-1 table exists at all.  The D registers
+    // of a lane are channels 8q + 4 half + e, so the layer-2 k slot (block m, half h, e) is channel 16m + 4h + (e & 3) + 8(e >> 2):
+    // the BF16 W2 images are stored in that order (ev2h_tile_geometry out[9] = 1), for every kernel mode.
+    constexpr bool L1M = (NS == 1) && !ROWS;
+#ifdef EV2H_FRAG_PIPE_ALL
+    constexpr bool FRAG_PIPE = true;
+#else
+    constexpr bool FRAG_PIPE = (NS == 1);
+#endif
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     char* wt0 = smem;
     char* wt1 = smem + Cfg::TILE;
     f32x4* sW1xT = reinterpret_cast<f32x4*>(smem + WBYTES);     // per 4 channels: x[4], y[4], z[4]
-    float* sb2 = reinterpret_cast<float*>(smem + WBYTES + C1 * 16);
+    float* sb2 = reinterpret_cast<float*>(smem + WBYTES + Cfg::W1B);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,21 +145,39 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
 
-    if constexpr (!ROWS) {
-        for (int i = tid; i < C1; i += SAB_THREADS) {
+    if constexpr (L1M) {
+        // A1 [C1][16 k] bf16 (one 32-byte row per channel), k slots as listed above
+        for (int i = tid; i < C1; i += WV * 64) {
+            const float4 w = p.W1x[i];
+            float k[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) k[j] = 0.f;
+            k[5] = k[8] = w.x; k[6] = k[9] = w.y; k[7] = k[10] = w.z;
+            if (p.feat) {
+                for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) k[12 + j] = k[j];
+                k[11] = p.b1[i];
+            }
+            unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { unsigned o[1]; split_planes<1>(k[2 * j], k[2 * j + 1], o); d[j] = o[0]; }
+        }
+    } else if constexpr (!ROWS) {
+        for (int i = tid; i < C1; i += WV * 64) {
             const float4 w = p.W1x[i];
             float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
             d[0] = w.x; d[4] = w.y; d[8] = w.z;
         }
     }
-    for (int i = tid; i < T2 * 32; i += SAB_THREADS) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
+    for (int i = tid; i < T2 * 32; i += WV * 64) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
     // F16X2: the accumulators hold (s1 / u2)(W2 h1 + b2) with the window's power of two s1; each wave keeps b2 s1 / u2 of its
     // window here, so that an accumulator tile is initialised by four LDS reads and no arithmetic
-    float* sbw = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + C1 * 16 + T2 * 32 * 4 + 16) + wave * (T2 * 32) : sb2;
+    float* sbw = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + Cfg::W1B + T2 * 32 * 4 + 16) + wave * (T2 * 32) : sb2;
 
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
     auto dma_tile = [&](const char* src, char* dst, int bytes) {
-        for (int off = wave * 1024; off < bytes; off += SAB_WAVES * 1024) {
+        for (int off = wave * 1024; off < bytes; off += WV * 1024) {
             if (off + lane * 16 < bytes)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // the algorithmic HBM traffic: 32 windows in flight per XCD do not fit the 4 MB L2)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nbx = p.nblk >> 3;
     const int g_end = RES ? min(ngroups, (xcd + 1) * p.per_xcd) : ngroups;
-  for (int g = (RES ? xcd * p.per_xcd + slot * SAB_WAVES : L * SAB_WAVES) + wave; RES ? g < g_end : true; g += nbx * SAB_WAVES) {
+  for (int g = (RES ? xcd * p.per_xcd + slot * WV : L * WV) + wave; RES ? g < g_end : true; g += nbx * WV) {
     const bool valid = g < ngroups;
     const int gg = valid ? g : ngroups - 1;
     const int b = gg / p.S;
@@ -211,7 +249,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     if (!ROWS && p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
     int nstrips = my_strips;
     if constexpr (!RES && !ROWS) {
-        int* s_strips = reinterpret_cast<int*>(smem + WBYTES + C1 * 16 + T2 * 32 * 4);
+        int* s_strips = reinterpret_cast<int*>(smem + WBYTES + Cfg::W1B + T2 * 32 * 4);
         if (tid == 0) *s_strips = 1;
         __syncthreads();
         if (lane == 0) atomicMax(s_strips, my_strips);
@@ -223,6 +261,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const bool dbgw = (blockIdx.x == 300 && tid == 0);
     const int dbg_strip = nstrips > 1 ? 1 : 0;
 #endif
+    // XPF (BF16 set abstraction): the neighbour gather of strip s + 1 -- index, then coordinates and feature row (or the first
+    // table chunk) -- is requested DURING strip s, so that a strip no longer starts with two dependent global-memory latencies
+    // (index -> row: 6 of the 28 us of a strip in the phase timeline, with one workgroup per CU and nothing else to run)
+    constexpr bool XPF = L1M;
+    f32x4 raw[4];                 // a lane's 16 gathered layer-1 values of the current chunk (XPF: survives into the next strip)
+    int idx_cur = 0, idx_nxt = 0;
+    float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), f0_cur = q_cur, f1_cur = q_cur;
+    if constexpr (XPF) {
+        idx_cur = gi[l31];
+        q_cur = p.pts4[(size_t)b * p.Npts + idx_cur];
+        if (p.feat) {
+            const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_cur) * p.ldf);
+            f0_cur = fr[0]; f1_cur = fr[1];
+        }
+    }
     for (int strip = 0; strip < nstrips; ++strip) {
         STAMP(0);
         if constexpr (!RES) {
@@ -241,10 +294,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
         }
         float dx = 0.f, dy = 0.f, dz = 0.f;
+        // a lane's j4-th float4 of a 32-channel chunk: channels 16 half + 4 j4 + (0..3), or -- BF16 -- 8 j4 + 4 half + (0..3) (the D
+        // layout of the layer-1 MFMA; row bases then carry no half offset)
+        auto qi = [&](int j4) { return NS == 1 ? 2 * j4 + half : j4; };
+        constexpr int HOFF = NS == 1 ? 0 : 16;
         const float4* prow = nullptr;
         const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
         float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
-        f32x4 raw[4];
+        u32x4 b1f = {0u, 0u, 0u, 0u};                      // L1M: the B operand of the layer-1 MFMA
         // ROWS: raw = (w0 T0 + w1 T1) + w2 T2 of chunk c (pointnet2_utils.py:303 applied to the layer-1 table; the table is stored
         // scaled by s1 in F16X2, so the blend is s1 H1 before the ReLU)
         f32x4 trw[ROWS ? 3 : 1][4];
@@ -252,7 +309,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int j = 0; j < ((ROWS && !DIRECT) ? 3 : 1); ++j)
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + j4);
+                for (int j4 = 0; j4 < 4; ++j4) trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + qi(j4));
         };
         auto blend = [&]() {
 #pragma unroll
@@ -263,26 +320,73 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                                         : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
         if constexpr (DIRECT) {
-            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp + 16 * half);
+            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp + HOFF * half);
             fetch(0);
             blend();
         } else if constexpr (ROWS) {
             const size_t gr = ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                trow[j] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + p.nn_idx[gr + j]) * p.ldp + 16 * half);
+                trow[j] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + p.nn_idx[gr + j]) * p.ldp + HOFF * half);
                 tw[j] = p.nn_w[gr + j];
             }
             fetch(0);
             blend();
         } else {
-            const int idx = gi[strip * 32 + l31];
-            const float4 q = p.pts4[(size_t)b * p.Npts + idx];
+            const int idx = XPF ? idx_cur : gi[strip * 32 + l31];
+            const float4 q = XPF ? q_cur : p.pts4[(size_t)b * p.Npts + idx];
+            if constexpr (XPF) idx_nxt = (strip + 1 < my_strips) ? gi[(strip + 1) * 32 + l31] : idx_cur;
             dx = __fsub_rn(q.x, ctr.x); dy = __fsub_rn(q.y, ctr.y); dz = __fsub_rn(q.z, ctr.z);
             if constexpr (NS == 2) { dx *= s1; dy *= s1; dz *= s1; }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
-            prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+            if constexpr (L1M) {
+                // B1: this lane's 8 k slots of its neighbour (half 0: k 0..7, half 1: k 8..15), hi / lo bf16 planes of the inputs
+                float f[8];
 #pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
+                if (p.feat) {
+                    f[0] = f0_cur.x; f[1] = f0_cur.y; f[2] = f0_cur.z; f[3] = f0_cur.w; f[4] = f1_cur.x;
+                } else {
+                    prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp);
+                    if (strip == 0) {          // (later strips: requested during the previous strip's layer 3)
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + qi(j4));
+                    }
+                }
+                auto lo_of = [](float x) { return x - __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, 0.f}, bf16x2)) << 16); };
+                const float va[8] = {f[0], f[1], f[2], f[3], f[4], lo_of(dx), lo_of(dy), lo_of(dz)};
+                const float vb[8] = {dx, dy, dz, 1.f, lo_of(f[0]), lo_of(f[1]), lo_of(f[2]), lo_of(f[3])};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    unsigned o[1];
+                    split_planes<1>(half ? vb[2 * w] : va[2 * w], half ? vb[2 * w + 1] : va[2 * w + 1], o);
+                    b1f[w] = o[0];
+                }
+            } else {
+                prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+            }
+        }
+        // BF16 set abstraction: layer 1 of chunk c as one MFMA (C = the table row in table mode)
+        auto layer1 = [&](int c) {
+            f32x16 acc;
+            if (p.feat) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = raw[r >> 2][r & 3];
+            }
+            const u32x4 a1 = *reinterpret_cast<const u32x4*>(smem + WBYTES + (32 * c + l31) * 32 + half * 16);
+            return mfma_planes<1>(a1, b1f, acc);
+        };
+        f32x16 d1;
+        if constexpr (L1M) {
+            d1 = layer1(0);
+            if (!p.feat && NC1 > 1) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + 8 + qi(j4));
+            }
         }
 
         // ---------------- layer 2 (contraction-chunk outer): h2[t] = D2[channel 32t + mfma_row(r,half)][neighbour]
@@ -309,12 +413,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             if constexpr (!RES) {
                 if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
             }
-            if (!ROWS && !Cfg::PREFETCH_P1 && c > 0) {
+            if (!ROWS && !L1M && !Cfg::PREFETCH_P1 && c > 0) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
             }
             // layer-1 finish in fp32, then split: lane's channels 32c + 16*half + [0,16) = k-slots of 2 MFMAs
             u32x4 bp[2][NS];
+            if constexpr (L1M) {
+                // ReLU on the packed bf16 pairs: one v_pk_max_i16 per pair (negative floats are negative int16 patterns)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    unsigned o[1];
+                    split_planes<1>(d1[2 * w], d1[2 * w + 1], o);
+                    bp[w >> 2][0][w & 3] = relu_pk_bf16(o[0]);
+                }
+            } else {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 const f32x4* wp = sW1xT + (8 * c + 4 * half + j4) * 3;
@@ -327,6 +440,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 if constexpr (DIRECT) {                  // the rows are the layer's input as it is (|v| < 2^15 by the scale)
                     split_planes<NS>(v[0], v[1], lo);
                     split_planes<NS>(v[2], v[3], hi);
+                } else if constexpr (NS == 1) {
+                    split_planes<NS>(v[0], v[1], lo);
+                    split_planes<NS>(v[2], v[3], hi);
+                    lo[0] = relu_pk_bf16(lo[0]); hi[0] = relu_pk_bf16(hi[0]);
                 } else if constexpr (NS == 2) {
                     split_planes<NS>(relu_sat_f16(v[0]), relu_sat_f16(v[1]), lo);
                     split_planes<NS>(relu_sat_f16(v[2]), relu_sat_f16(v[3]), hi);
@@ -340,9 +457,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
                 }
             }
+            }
             if constexpr (ROWS) {
                 if (c + 1 < NC1) fetch(c + 1);      // in flight under this chunk's MFMAs, blended after them
-            } else if (Cfg::PREFETCH_P1 && c + 1 < NC1) {
+            } else if (!L1M && Cfg::PREFETCH_P1 && c + 1 < NC1) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
             }
@@ -351,24 +469,52 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             // the 2*T2 (k-block m, tile t) groups are taken two at a time and their MFMAs alternate between the two tiles'
             // accumulators: anything issued between two MFMAs on the SAME accumulator (here the next fragment reads) costs
             // ~43 cycles, between MFMAs on different accumulators ~6 (MI355X_MICROARCH.md, latency table)
+            // FRAG_PIPE (BF16): the fragment reads of group pr + 1 are issued BEFORE the MFMAs of group pr (two register sets, order
+            // pinned with scheduling barriers).  Left to itself the compiler emitted read, read, s_waitcnt lgkmcnt(0), MFMA, MFMA per
+            // group -- the full LDS latency in front of every MFMA pair, which with ONE product per operand pair is most of a tile
+            // step (phase timeline, profiles/r4_sa_timeline.txt: 1.0-1.7 us per 14-MFMA chunk whose MFMAs take 0.22 us).
+            auto ld2 = [&](int pr, u32x4 (&x0)[NS], u32x4 (&x1)[NS]) {
+                const int m0 = (2 * pr) / T2, t0 = (2 * pr) % T2, m1 = (2 * pr + 1) / T2, t1 = (2 * pr + 1) % T2;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    x0[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t0 * RS2 + s * 64 + m0 * 16);
+                    x1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t1 * RS2 + s * 64 + m1 * 16);
+                }
+            };
+            u32x4 fa[2][2][NS];
+            if constexpr (FRAG_PIPE) ld2(0, fa[0][0], fa[0][1]);
 #pragma unroll
             for (int pr = 0; pr < T2; ++pr) {
                 const int m0 = (2 * pr) / T2, t0 = (2 * pr) % T2, m1 = (2 * pr + 1) / T2, t1 = (2 * pr + 1) % T2;
-                u32x4 a0[NS], a1[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    a0[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t0 * RS2 + s * 64 + m0 * 16);
-                    a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t1 * RS2 + s * 64 + m1 * 16);
+                if constexpr (FRAG_PIPE) {
+                    if (pr + 1 < T2) ld2(pr + 1, fa[(pr + 1) & 1][0], fa[(pr + 1) & 1][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    ld2(pr, fa[pr & 1][0], fa[pr & 1][1]);
                 }
+                u32x4 (&a0)[NS] = fa[pr & 1][0];
+                u32x4 (&a1)[NS] = fa[pr & 1][1];
 #pragma unroll
                 for (int j = 0; j < PL::NPROD; ++j) {
                     // PACK4: the last tile's high-plane image carries its low plane in rows 8..11 (see SaBCfg)
                     if (!(Cfg::PACK4 && t0 == T2 - 1 && PL::A[j] == 1)) h2[t0] = mfma_planes<NS>(a0[PL::A[j]], bp[m0][PL::B[j]], h2[t0]);
                     if (!(Cfg::PACK4 && t1 == T2 - 1 && PL::A[j] == 1)) h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
                 }
+                if constexpr (FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (ROWS) {
                 if (c + 1 < NC1) blend();
+            }
+            if constexpr (L1M) {
+                // next chunk's layer 1: issued behind this chunk's MFMAs, converted at the top of the next iteration; its table row
+                // (table mode) was loaded one iteration ago, the row after it is requested now
+                if (c + 1 < NC1) {
+                    d1 = layer1(c + 1);
+                    if (!p.feat && c + 2 < NC1) {
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
+                    }
+                }
             }
             STAMP(4 + 4 * c);
             if constexpr (!RES) {
@@ -382,6 +528,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
 
         STAMP(38);
+        if constexpr (XPF) {
+            // next strip's coordinates and feature row / first table chunk: its index arrived long ago; `raw` is free again
+            if (strip + 1 < my_strips) {
+                q_cur = p.pts4[(size_t)b * p.Npts + idx_nxt];
+                if (p.feat) {
+                    const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_nxt) * p.ldf);
+                    f0_cur = fr[0]; f1_cur = fr[1];
+                } else {
+                    const float4* pn = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx_nxt) * p.ldp);
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(pn + qi(j4));
+                }
+                idx_cur = idx_nxt;
+            }
+        }
         if constexpr (Cfg::PACK4) {          // wl*xh of the leftover channels arrived in D rows 8..11 = registers 4..7
 #pragma unroll
             for (int r = 0; r < 4; ++r) { h2[T2 - 1][r] += h2[T2 - 1][r + 4]; h2[T2 - 1][r + 4] = 0.f; }
@@ -394,6 +555,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int k = 0; k < 8; ++k) {
                 unsigned o[NS];
                 if constexpr (NS == 2) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
+                else if constexpr (NS == 1) { split_planes<NS>(h2[t][2 * k], h2[t][2 * k + 1], o); o[0] = relu_pk_bf16(o[0]); }     // (u2 = 1: no factor)
                 else split_planes<NS>(relu_bits(h2[t][2 * k] * c2), relu_bits(h2[t][2 * k + 1] * c2), o);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
@@ -443,18 +605,33 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
             const char* pb = cur + l31 * RS3 + (8 * half) * 2;
+            constexpr int NG3 = 2 * (T2 - 1) + Cfg::M_LAST;       // live (tile, k-block) groups of the contraction
+            auto ld3 = [&](int g, u32x4 (&x)[NS], u32x4 (&x1)[TPS == 2 ? NS : 1]) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    x[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (16 * g) * 2);
+                    if constexpr (TPS == 2) x1[s] = *reinterpret_cast<const u32x4*>(pb + Cfg::TB3 + s * (C2P * 2) + (16 * g) * 2);
+                }
+            };
+            u32x4 fw[2][NS], fw1[2][TPS == 2 ? NS : 1];
+            if constexpr (FRAG_PIPE) ld3(0, fw[0], fw1[0]);
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     if (t < T2 - 1 || m < Cfg::M_LAST) {
-                        u32x4 a[NS], w[NS], w1[TPS == 2 ? NS : 1];
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            a[s] = h2p[s][t][m];
-                            w[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (32 * t + 16 * m) * 2);
-                            if constexpr (TPS == 2) w1[s] = *reinterpret_cast<const u32x4*>(pb + Cfg::TB3 + s * (C2P * 2) + (32 * t + 16 * m) * 2);
+                        const int g = 2 * t + m;
+                        if constexpr (FRAG_PIPE) {
+                            if (g + 1 < NG3) ld3(g + 1, fw[(g + 1) & 1], fw1[(g + 1) & 1]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            ld3(g, fw[g & 1], fw1[g & 1]);
                         }
+                        u32x4 a[NS];
+                        u32x4 (&w)[NS] = fw[g & 1];
+                        u32x4 (&w1)[TPS == 2 ? NS : 1] = fw1[g & 1];
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) a[s] = h2p[s][t][m];
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
 #pragma unroll
                         for (int j = 0; j < PL::NPROD; ++j) {
@@ -467,6 +644,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                                 else acc = mfma_planes<NS>(a[PL::A[j]], w[PL::B[j]], acc);
                             }
                         }
+                        if constexpr (FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -617,6 +795,7 @@ int fill_geometry(int out[10]) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     out[0] = Cfg::T2; out[1] = Cfg::C2P; out[2] = Cfg::RS2; out[3] = Cfg::RS3; out[4] = Cfg::TB2; out[5] = Cfg::TB3;
     out[8] = Cfg::PACK4 ? Cfg::REM : 0;
+    out[9] = NS == 1 ? 1 : 0;          // BF16: the W2 images hold their k slots in the layer-1 D-register order (see L1M in the kernel)
     return EV2H_OK;
 }
 template <int NS>
@@ -681,6 +860,14 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
+    if (d->feat) {
+        EV2H_CHECK_ARG(d->precision == EV2H_PREC_BF16 && d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 && d->ldf >= 8 && (d->ldf % 4) == 0 &&
+                       d->ldw1f >= d->nfeat);
+        p.feat = d->feat; p.ldf = d->ldf; p.W1f = d->W1f; p.ldw1f = d->ldw1f; p.b1 = d->b1; p.nfeat = d->nfeat;
+    } else {
+        EV2H_CHECK_ARG(d->P1 != nullptr);
+    }
+    if (d->precision == EV2H_PREC_BF16) EV2H_CHECK_ARG(p.u2 == 1.f);      // (the BF16 layer-2 epilogue applies no factor)
     if (d->precision == EV2H_PREC_F16X2) {
         p.out_amax = d->out_amax;
         if (d->p1_scale) {

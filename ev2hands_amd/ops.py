@@ -136,18 +136,28 @@ def make_w_image(W: torch.Tensor, precision: str, rows: int = 128):
 
 
 def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None,
-               p1_scale=None, p1_amax=None, dmax: float = 0.0, out_amax=None) -> torch.Tensor:
+               p1_scale=None, p1_amax=None, dmax: float = 0.0, out_amax=None, feat=None, W1f=None, b1=None) -> torch.Tensor:
     """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3].
     W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); 16-bit tile images are built here when needed.
     cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped.
     p1_scale [B] float32 / p1_amax [B] range record / dmax / out_amax: the F16X2 range arguments of ev2h_sa_desc (P1 then
     holds p1_scale[b] * table)."""
-    B, Npts, C1 = P1.shape
+    if feat is not None:
+        # "bf16" only: layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
+        # b1 [C1] -- no table (P1 may be None)
+        B, Npts, C1 = feat.shape[0], feat.shape[1], W1x.shape[0]
+        dev = feat.device
+    else:
+        B, Npts, C1 = P1.shape
+        dev = P1.device
     S, K = gidx.shape[1], gidx.shape[2]
     C3 = W3.shape[0]
-    out = torch.empty(B, S, C3, device=P1.device, dtype=torch.float32)
+    out = torch.empty(B, S, C3, device=dev, dtype=torch.float32)
     d = _lib.SaDesc()
-    d.P1, d.ldp, d.pts4, d.ctr4, d.gidx = P1.data_ptr(), C1, pts4.data_ptr(), ctr4.data_ptr(), gidx.data_ptr()
+    d.P1, d.ldp, d.pts4, d.ctr4, d.gidx = _lib.ptr(P1), C1, pts4.data_ptr(), ctr4.data_ptr(), gidx.data_ptr()
+    if feat is not None:
+        W1fc, b1c = W1f.contiguous(), b1.contiguous()
+        d.feat, d.ldf, d.W1f, d.ldw1f, d.b1, d.nfeat = feat.data_ptr(), feat.shape[2], W1fc.data_ptr(), W1fc.shape[1], b1c.data_ptr(), W1fc.shape[1]
     d.W1x, d.W2, d.b2, d.W3, d.b3 = W1x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr()
     d.out, d.ldo = out.data_ptr(), C3
     d.B, d.Npts, d.S, d.K, d.C1, d.C2, d.C3 = B, Npts, S, K, C1, C2, C3
@@ -166,7 +176,7 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
         from .pack import NS_OF, sa_bf16_images
         i2, i3, d.w2_unscale, d.w3_unscale = sa_bf16_images(W2[:C2].detach().cpu().double().numpy(),
                                                             W3[:, :C2].detach().cpu().double().numpy(), NS_OF[precision])
-        keep = [torch.from_numpy(i2).to(P1.device), torch.from_numpy(i3).to(P1.device)]
+        keep = [torch.from_numpy(i2).to(dev), torch.from_numpy(i3).to(dev)]
         d.W2s, d.W3s = keep[0].data_ptr(), keep[1].data_ptr()
     _lib.check(_lib.lib().ev2h_sa_mlp_max(C.byref(d), _st()), "ev2h_sa_mlp_max")
     return out

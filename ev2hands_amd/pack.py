@@ -164,4 +164,4 @@ def kernel_geometry(C1: int, C2: int, C3: int, ns: int) -> dict:
     """Tile-image geometry of a chain as the KERNELS define it (ev2h_tile_geometry)"""
     out = (C.c_int * 10)()
     _lib.check(_lib.lib().ev2h_tile_geometry(C1, C2, C3, ns, out), "ev2h_tile_geometry")
-    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK", "LEFTOVER"), out))
+    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK", "LEFTOVER", "W2PERM"), out))

@@ -200,6 +200,14 @@ typedef struct ev2h_sa_desc {
     float w2_norm;               /* max row L1 norm of W2                                                               */
     float b2_max;                /* max |b2|                                                                            */
     uint32_t* out_amax;          /* [B] range record of `out` (atomicMax), optional                                     */
+    /* BF16 only, optional: layer 1 straight from the raw feature rows, on the matrix pipe -- P1 is then not needed (may be NULL) and
+     * no layer-1 table has to be computed or gathered: feat [B][Npts][ldf] (first nfeat <= 5 columns used, ldf >= 8: the forward's
+     * feat8 / hf8 rows), W1f [C1][ldw1f] and b1 [C1] the folded layer-1 feature weights and bias of this branch.  Inputs enter as
+     * two bf16 planes (16 bits), weights as bf16. */
+    const float* feat; int ldf;
+    const float* W1f; int ldw1f;
+    const float* b1;
+    int nfeat;
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
@@ -247,7 +255,9 @@ int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
  * W2 / W3 tile), TB2, TB3 (bytes per tile), GEMM RS (bytes per row of a dense W image tile), GEMM BK (k columns per tile),
  * LEFTOVER (0, or the 1..4 channels beyond the last full 32-channel tile whose plane products share MFMAs: the images then carry,
  * in the HIGH plane, the low plane of the leftover W2 rows in rows 8..11 of the last tile and [wh | wh | wl | 0] in the last 16
- * k-slots of every W3 row -- csrc/sa_mlp_bf16.hip SaBCfg::PACK4), 0 }.
+ * k-slots of every W3 row -- csrc/sa_mlp_bf16.hip SaBCfg::PACK4), W2PERM (1 = BF16: inside every 32-column chunk of a W2 image,
+ * position 16h + 8m + e holds input channel 16m + 4h + (e & 3) + 8(e >> 2) -- the D-register order of the layer-1 MFMA; 0 = plain
+ * channel order) }.
  * The library's own packer (ev2h_pack_weights, ev2h_pack_sa_images) asserts its layout against this on every pack, so the kernels
  * and the packer cannot drift apart silently; a caller that builds images itself can do the same.  Needs no GPU. */
 int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10]);

@@ -136,7 +136,7 @@ def kernel_geometry(C1: int, C2: int, C3: int, ns: int) -> dict:
     GBCfg) -- the one source of truth the image builders below are asserted against."""
     out = (C.c_int * 10)()
     _lib.check(_lib.lib().ev2h_tile_geometry(C1, C2, C3, ns, out), "ev2h_tile_geometry")
-    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK", "LEFTOVER"), out))
+    return dict(zip(("T2", "C2P", "RS2", "RS3", "TB2", "TB3", "GEMM_RS", "GEMM_BK", "LEFTOVER", "W2PERM"), out))
 
 
 def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
@@ -153,6 +153,11 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     left = g["LEFTOVER"]               # 0, or the 1..4 channels past the last full tile whose plane products share MFMAs (SaBCfg::PACK4)
     base = 32 * (T2 - 1)
     W2p = _pad(W2, T2 * 32, C1)
+    if g.get("W2PERM"):                # BF16: k slots of every 32-column chunk in the D-register order of the layer-1 MFMA
+        pos = np.arange(32)
+        h, m, e = pos // 16, (pos % 16) // 8, pos % 8
+        src = 16 * m + 4 * h + (e & 3) + 8 * (e >> 2)
+        W2p = np.concatenate([W2p[:, 32 * c:32 * c + 32][:, src] for c in range(C1 // 32)], 1)
     p2 = split_bf16_planes(W2p, ns)
     if left:
         assert ns == 2 and C2 - base == left and left <= 4
