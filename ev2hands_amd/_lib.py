@@ -101,7 +101,7 @@ EXPORTS = [
     "ev2h_pack_weights", "ev2h_packed_free", "ev2h_packed_weights", "ev2h_packed_bytes", "ev2h_packed_tensor_count", "ev2h_packed_tensor",
     "ev2h_packed_equalization_count", "ev2h_packed_equalization", "ev2h_packed_weight_spread_count", "ev2h_packed_weight_spread", "ev2h_pack_sa_image_bytes", "ev2h_pack_sa_images",
     "ev2h_pack_gemm_image_bytes", "ev2h_pack_gemm_image", "ev2h_plane_unscale",
-    "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_collision_penalty",
+    "ev2h_event_window_build", "ev2h_event_window_timesort", "ev2h_event_window_sample", "ev2h_joint_metrics", "ev2h_mesh_collisions", "ev2h_mesh_collisions_ws", "ev2h_mesh_collisions_scratch_bytes", "ev2h_collision_penalty",
 ]
 
 _lib = None
@@ -155,6 +155,9 @@ def lib() -> C.CDLL:
     L.ev2h_event_window_sample.argtypes = [vp, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_joint_metrics.argtypes = [vp, vp, vp, ci, ci, ci, C.c_double, vp, vp, vp, vp, vp, vp]
     L.ev2h_mesh_collisions.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp]
+    L.ev2h_mesh_collisions_ws.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, ci, vp, vp, ci, vp, C.c_size_t, vp]
+    L.ev2h_mesh_collisions_scratch_bytes.restype = C.c_size_t
+    L.ev2h_mesh_collisions_scratch_bytes.argtypes = [ci, ci]
     L.ev2h_collision_penalty.argtypes = [vp, vp, vp, vp, ci, ci, ci, C.c_float, C.c_double, vp, vp, ci, vp, vp]
     L.ev2h_range_report_entries.argtypes = [C.POINTER(C.c_char_p), ci]
     L.ev2h_range_report.argtypes = [vp, ci, ci, vp, vp]

@@ -43,10 +43,25 @@ def mesh_collisions(verts_left: torch.Tensor, verts_right: torch.Tensor, faces_l
     nf = fl.shape[0]
     counts = torch.empty(B, device=dev, dtype=torch.int32)
     pairs = torch.empty(B, max_pairs, 2, device=dev, dtype=torch.int32) if max_pairs > 0 else None
-    _lib.check(_lib.lib().ev2h_mesh_collisions(vl.data_ptr(), vr.data_ptr(), fl.data_ptr(), fr.data_ptr(), B, nv, nf, float(scale),
-                                               max_pairs, _lib.ptr(pairs), counts.data_ptr(), int(max_per_triangle), _lib.stream_handle()),
-               "ev2h_mesh_collisions")
+    L = _lib.lib()
+    # a scratch buffer lets the library split a window's row blocks over two workgroups when the batch alone cannot fill the chip
+    scratch = _scratch(L.ev2h_mesh_collisions_scratch_bytes(B, nf), dev) if B <= 128 else None
+    _lib.check(L.ev2h_mesh_collisions_ws(vl.data_ptr(), vr.data_ptr(), fl.data_ptr(), fr.data_ptr(), B, nv, nf, float(scale),
+                                         max_pairs, _lib.ptr(pairs), counts.data_ptr(), int(max_per_triangle), _lib.ptr(scratch),
+                                         scratch.numel() if scratch is not None else 0, _lib.stream_handle()),
+               "ev2h_mesh_collisions_ws")
     return counts, pairs
+
+
+_SCRATCH = {}
+
+
+def _scratch(nbytes: int, dev) -> torch.Tensor:
+    """per-device scratch for ev2h_mesh_collisions_ws, grown on demand (calls on one stream are ordered, so it is shared)"""
+    t = _SCRATCH.get(str(dev))
+    if t is None or t.numel() < nbytes:
+        t = _SCRATCH[str(dev)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return t
 
 
 def compute_non_collision_score(verts_left_pred, faces_left, verts_right_pred, faces_right, max_collisions: int = 8):

@@ -16,6 +16,7 @@
 // -- and their verdicts are applied in queue order by the lane that owns the row, so the accepted set, the per-triangle cap and
 // the pair order are exactly those of the sequential walk.  Two passes (count, prefix sum over the rows, write) make the pair
 // list deterministic.
+#include <cstdlib>
 #include "common.hpp"
 #include "ev2hands_hip.h"
 
@@ -32,6 +33,11 @@ struct ColP {
     int32_t* pairs;                            // [B][max_pairs][2] or null
     int32_t* counts;                           // [B]
     int cap;                                   // per-triangle cap on recorded pairs (the BVH's max_collisions), 0 = none
+    // Several workgroups per window (ev2h_mesh_collisions_ws): workgroup w of nsplit takes every nsplit-th wave's row blocks;
+    // the per-row counts then meet in global memory (rowcnt [B][2 nf + 1]) and a second launch (phase 1) forms the prefix sums,
+    // the window's count and the compacted list; without the one-walk list a third launch (phase 2) writes the pairs.
+    int nsplit, phase;
+    int32_t* rowcnt;
 };
 
 struct V3 { double x, y, z; };
@@ -75,18 +81,23 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     int* spart = srow + F2 + 1;                                 // [COL_THREADS] scan scratch
     int* squeue = spart + COL_THREADS + (threadIdx.x >> 6) * 128;   // [waves][128] this wave's candidates: (lane << 16) | column
     float* sblk = reinterpret_cast<float*>(spart + COL_THREADS + (COL_THREADS >> 6) * 128);   // [nblk][6] box of every 64-triangle block
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wgs = p.phase == 1 ? 1 : p.nsplit;              // (phase 1 runs one workgroup per window)
+    const int b = blockIdx.x / wgs, wg = blockIdx.x % wgs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* grow = p.rowcnt ? p.rowcnt + (size_t)b * (F2 + 1) : nullptr;
 
+    if (p.phase != 1)
     for (int i = tid; i < 3 * V2; i += COL_THREADS) {
         const int v = i / 3, c = i - 3 * v;
         const float x = v < p.nv ? p.vl[((size_t)b * p.nv + v) * 3 + c] : p.vr[((size_t)b * p.nv + (v - p.nv)) * 3 + c];
         sv[i] = __fmul_rn(x, p.scale);                          // float32 multiply like `.numpy() * 1000`
     }
+    if (p.phase != 1)
     for (int i = tid; i < 3 * F2; i += COL_THREADS) {
         const int f = i / 3, c = i - 3 * f;
         sf[i] = f < p.nf ? p.fl[f * 3 + c] : p.fr[(f - p.nf) * 3 + c] + p.nv;
     }
     __syncthreads();
+    if (p.phase != 1)
     for (int f = tid; f < F2; f += COL_THREADS) {
         float lo[3], hi[3];
 #pragma unroll
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     // their order and therefore the counts, caps and pair lists are exactly those of the full walk.  Mesh faces are stored
     // locally coherent (a block is a patch of the surface), and the two hands are usually apart: a hand-like pair of meshes
     // keeps ~1/8 of the block pairs (profiles/r3_collision_timing.txt); random triangle soup keeps all of them.
-    {
+    if (p.phase != 1) {
         const int nblk_ = (F2 + 63) >> 6;
         for (int kb = wave; kb < nblk_; kb += (COL_THREADS >> 6)) {
             const int f = kb * 64 + lane;
@@ -134,8 +145,15 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     // for half the separating-axis tests.
     const bool one_walk = out && p.cap > 0 && (long)p.max_pairs >= (long)F2 * p.cap;
 
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int rb = wave; rb < nblk; rb += nwaves) {
+    // Row blocks are dealt to the waves (of all the window's workgroups) in snake order: block rb scans the column blocks rb .. nblk-1,
+    // so dealing them round-robin gave the first wave 100 column blocks and the last 54 (49 row blocks, 16 waves); boustrophedon
+    // rounds level that (84 / 70), and with two workgroups per window no wave has more than block 0's 49.  A row's result does not
+    // depend on who computes it.
+    const int NW = nwaves * p.nsplit, gw = wg * nwaves + wave;
+    auto walk = [&](int pass) {
+        for (int rnd = 0; rnd * NW < nblk; ++rnd) {
+            const int rb = rnd * NW + ((rnd & 1) ? NW - 1 - gw : gw);
+            if (rb >= nblk) continue;
             const int i = rb * 64 + lane;
             const bool valid = i < F2;
             const int ii = valid ? i : F2 - 1;
@@ -197,8 +215,21 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
             }
             }
             while (qn > 0) drain(min(qn, 64));
-            if (!pass && valid) srow[i] = cnt;
+            if (!pass && valid) { if (p.nsplit > 1) grow[i] = cnt; else srow[i] = cnt; }
         }
+    };
+    if (p.nsplit > 1 && p.phase == 0) { walk(0); return; }
+    if (p.nsplit > 1 && p.phase == 2) {                          // bases = the exclusive prefix phase 1 left in rowcnt
+        for (int r = tid; r <= F2; r += COL_THREADS) srow[r] = grow[r];
+        __syncthreads();
+        walk(1);
+        return;
+    }
+    if (p.nsplit > 1) {                                          // phase 1: the row counts of all workgroups
+        for (int r = tid; r < F2; r += COL_THREADS) srow[r] = grow[r];
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (p.nsplit == 1) walk(pass);
         if (pass) break;
         __syncthreads();
         // exclusive prefix sum of srow[0..F2): each thread sums a contiguous chunk, Hillis-Steele over the chunk totals
@@ -219,6 +250,10 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
         if (tid == COL_THREADS - 1) { p.counts[b] = spart[tid]; srow[F2] = spart[tid]; }
         if (!out) break;                                        // counts only: the second walk would repeat every test for nothing
         __syncthreads();
+        if (p.nsplit > 1 && !one_walk) {                         // phase 2 (another launch) writes the pairs at these bases
+            for (int r = tid; r <= F2; r += COL_THREADS) grow[r] = srow[r];
+            break;
+        }
         if (one_walk) {
             // in-place compaction of the per-row slot ranges: entry e = (row r = e / cap, k = e % cap) is live iff k < cnt_r and moves
             // to srow[r] + k <= e
@@ -322,20 +357,54 @@ extern "C" int ev2h_collision_penalty(const float* verts_left, const float* vert
     return EV2H_OK;
 }
 
-extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left,
-                                    const int32_t* faces_right, int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs,
-                                    int32_t* counts, int max_per_triangle, ev2h_stream_t stream) {
+extern "C" size_t ev2h_mesh_collisions_scratch_bytes(int B, int nf) {
+    return (B > 0 && nf > 0) ? (size_t)B * (2 * (size_t)nf + 1) * sizeof(int32_t) : 0;
+}
+
+extern "C" int ev2h_mesh_collisions_ws(const float* verts_left, const float* verts_right, const int32_t* faces_left,
+                                       const int32_t* faces_right, int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs,
+                                       int32_t* counts, int max_per_triangle, void* scratch, size_t scratch_bytes, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(verts_left && verts_right && faces_left && faces_right && counts);
     EV2H_CHECK_ARG(B > 0 && nv >= 3 && nv <= COL_MAX_V && nf >= 1 && nf <= COL_MAX_F && max_pairs >= 0 && (pairs || max_pairs == 0));
     EV2H_CHECK_ARG(max_per_triangle >= 0);
-    ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts, max_per_triangle};
+    ColP p{verts_left, verts_right, faces_left, faces_right, nv, nf, scale, max_pairs, pairs, counts, max_per_triangle, 1, 0, nullptr};
     const size_t lds = (size_t)(3 * 2 * nv) * 4 + (size_t)(3 * 2 * nf) * 4 + (size_t)(6 * 2 * nf) * 4 + (size_t)(2 * nf + 1) * 4 +
                        COL_THREADS * 4 + (COL_THREADS / 64) * 128 * 4 + (size_t)((2 * nf + 63) / 64) * 6 * 4;
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024)););
+    // One 1024-thread workgroup (142 KB of LDS) per window fills one CU: below 256 windows CUs idle (BASELINE config 5 runs B = 128 per
+    // GPU).  With a scratch buffer a window's row blocks are split over two workgroups (more cannot help: row block 0 alone scans all
+    // 49 column blocks).  EV2H_COLLISION_SPLIT=1 forces one workgroup (A/B).
+    static const int forced = getenv("EV2H_COLLISION_SPLIT") ? atoi(getenv("EV2H_COLLISION_SPLIT")) : 0;
+    int nsplit = (scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf) && B <= 128) ? 2 : 1;
+    if (forced == 1 || (forced == 2 && scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf))) nsplit = forced;
+    if (nsplit == 1) {
+        mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+        EV2H_CHECK_LAUNCH();
+        return EV2H_OK;
+    }
+    p.nsplit = nsplit;
+    p.rowcnt = static_cast<int32_t*>(scratch);
+    p.phase = 0;
+    mesh_collision_kernel<<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+    EV2H_CHECK_LAUNCH();
+    p.phase = 1;
     mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
+    const bool one_walk = pairs && max_per_triangle > 0 && (long)max_pairs >= (long)(2 * nf) * max_per_triangle;
+    if (pairs && !one_walk) {
+        p.phase = 2;
+        mesh_collision_kernel<<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+        EV2H_CHECK_LAUNCH();
+    }
     return EV2H_OK;
+}
+
+extern "C" int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left,
+                                    const int32_t* faces_right, int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs,
+                                    int32_t* counts, int max_per_triangle, ev2h_stream_t stream) {
+    return ev2h_mesh_collisions_ws(verts_left, verts_right, faces_left, faces_right, B, nv, nf, scale, max_pairs, pairs, counts, max_per_triangle,
+                                   nullptr, 0, stream);
 }

@@ -653,7 +653,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     // (q1's range record is only needed by the unfolded second convolution: the folded form reads q1 in fp32)
+    prof_begin("qconv0", st);
     RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, attn_unfolded() ? rg(R_L0, N, R_Q1, N) : rg(R_L0, N), nullptr, 0, 0, 3, N));
+    prof_end("qconv0", st);
     // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
     // over the points (ev2h_attn_sim_folded): q2 is never formed
     const bool unfolded = attn_unfolded();

@@ -352,6 +352,13 @@ int ev2h_joint_metrics(const float* j3d_left, const float* j3d_right, const doub
 int ev2h_mesh_collisions(const float* verts_left, const float* verts_right, const int32_t* faces_left, const int32_t* faces_right,
                          int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs, int32_t* counts, int max_per_triangle,
                          ev2h_stream_t stream);
+/* The same search with a caller-owned scratch buffer (device, ev2h_mesh_collisions_scratch_bytes(B, nf) bytes): with at most 128
+ * windows the row blocks of a window are then split over TWO workgroups (one 1024-thread workgroup with 142 KB of LDS per window
+ * leaves half of the 256 CUs idle at BASELINE config 5's 128 windows per GPU); counts and pair lists are identical entry for entry. */
+size_t ev2h_mesh_collisions_scratch_bytes(int B, int nf);
+int ev2h_mesh_collisions_ws(const float* verts_left, const float* verts_right, const int32_t* faces_left, const int32_t* faces_right,
+                            int B, int nv, int nf, float scale, int max_pairs, int32_t* pairs, int32_t* counts, int max_per_triangle,
+                            void* scratch, size_t scratch_bytes, ev2h_stream_t stream);
 /* max_per_triangle > 0: at most that many pairs (i, j > i) are counted and listed per triangle i, the first ones in j order -- the
  * role of the reference BVH's `max_collisions` (8 in evaluate_ev2hands_r.py:131, 16 in losses.py:62).  Which pairs the reference's
  * tree keeps beyond its cap depends on its traversal order (not reproducible); the two agree whenever no triangle exceeds the cap. */
@@ -531,7 +538,8 @@ int ev2h_range_report(void* workspace, int B, int N, uint32_t* counts, ev2h_stre
 
 /* Measurement hook (bench.py): record caller-owned hipEvent_t pairs around ONE launch site of
  * ev2h_forward, on the forward's stream.  tag = "<module>.<branch>" with module in {sa1, sa2, manoL,
- * manoR} (the fused set-abstraction kernels).  Call i uses pair i % n.  tag == NULL disables. */
+ * manoR} (the fused set-abstraction kernels), "fp1" (the fused feature-propagation chain) or "qconv0" (the k = 3 query
+ * convolution GEMM of both hands, TEHNet.py:150-153).  Call i uses pair i % n.  tag == NULL disables. */
 int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, int n);
 
 /* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in

@@ -234,3 +234,45 @@ def test_gpu_capped_pair_list_one_walk_equals_two_walks_and_the_oracle(cap):
         m = min(n, F2 * cap - 1)
         assert np.array_equal(p2[b, :m].cpu().numpy(), ref[:m])
     assert int(c1[0]) == 0 and int(c1[2]) > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh", ["surface", "soup"])
+def test_gpu_two_workgroups_per_window_equal_one(mesh):
+    """ev2h_mesh_collisions_ws with a scratch buffer splits a window's row blocks over two workgroups (B <= 128: BASELINE config 5
+    runs 128 windows per GPU on 256 CUs); without one it is the single-workgroup search.  Counts and pair lists must be identical
+    entry for entry in all three forms of the call: count only, capped one-walk list, uncapped / short two-walk list."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    from ev2hands_amd import _lib, synth
+    from ev2hands_amd.mano import ManoHand
+    B, nv, nf = 6, 778, 1538
+    make = synth.synth_mano_surface_assets if mesh == "surface" else synth.synth_mano_assets
+    hands = {s: ManoHand(make(s, 2), "cuda") for s in ("left", "right")}
+    g = lambda n, sc: torch.from_numpy(synth.hash_normal("c" + str(n), (B, n), 7) * sc).float().cuda()      # noqa: E731
+    out = {s: hands[s](g(3, 0.4), g(6, 0.6), g(10, 0.5), g(3, 0.01)) for s in hands}
+    vl, vr = out["left"].vertices.contiguous(), (out["right"].vertices + torch.tensor([0.03, 0.0, 0.0], device="cuda")).contiguous()
+    fl = torch.as_tensor(np.asarray(hands["left"].faces).astype(np.int32)).cuda()
+    fr = torch.as_tensor(np.asarray(hands["right"].faces).astype(np.int32)).cuda()
+    L = _lib.lib()
+    scratch = torch.empty(L.ev2h_mesh_collisions_scratch_bytes(B, nf), dtype=torch.uint8, device="cuda")
+
+    def run(max_pairs, cap, ws):
+        counts = torch.full((B,), -1, device="cuda", dtype=torch.int32)
+        pairs = torch.full((B, max(max_pairs, 1), 2), -1, device="cuda", dtype=torch.int32)
+        _lib.check(L.ev2h_mesh_collisions_ws(vl.data_ptr(), vr.data_ptr(), fl.data_ptr(), fr.data_ptr(), B, nv, nf, 1000.0, max_pairs,
+                                             pairs.data_ptr() if max_pairs else None, counts.data_ptr(), cap,
+                                             scratch.data_ptr() if ws else None, scratch.numel() if ws else 0, _lib.stream_handle()), "ws")
+        torch.cuda.synchronize()
+        return counts.cpu(), pairs.cpu()
+
+    for max_pairs, cap in ((0, 8), (2 * nf * 16, 16), (5000, 0), (2 * nf * 2 - 1, 2)):
+        c1, p1 = run(max_pairs, cap, False)
+        c2, p2 = run(max_pairs, cap, True)
+        assert torch.equal(c1, c2), (max_pairs, cap, c1, c2)
+        for b in range(B):
+            n = min(int(c1[b]), max_pairs)
+            assert torch.equal(p1[b, :n], p2[b, :n]), (max_pairs, cap, b)
+    print(f"{mesh}: pairs per window {c1.tolist()}")
+    assert int(c1.max()) > 0
