@@ -462,10 +462,15 @@ struct GOCfg {
     static constexpr int LDS_BYTES = A_BYTES + B_BYTES;
 };
 
-template <int NS, bool TAP3>
+// PIPE (small grids only, not TAP3): two LDS buffers; the X rows and the W tile of step k + 1 are requested BEFORE the MFMAs of step
+// k and written behind them.  With three workgroups per CU the other two hide a workgroup's load -> split -> barrier chain; a launch
+// of 2..8 workgroups (one window at a time: every M = 128 B layer) has nobody to hide it, and its time is (K / 32) x that chain.
+// Same tiles, same MFMA order: bit-identical to the single-buffer kernel, so the choice (by launch size) never shows in a result.
+template <int NS, bool TAP3, bool PIPE = false>
 __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP p, const char* __restrict__ Ws) {
     using Cfg = GOCfg<NS, TAP3>;
     constexpr int RS = Cfg::RS;
+    static_assert(!(PIPE && TAP3), "the pipelined variant is for the plain K loop");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;
     char* sB = smem + Cfg::A_BYTES;
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
                      "global_load_dwordx4 %2, %5, off\n\tglobal_load_dwordx4 %3, %5, off offset:16"
                      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(g), "v"(g2) : "memory");
     };
-    auto gload = [&](int kt) {
+    auto gload = [&](int kt, f32x4 (&dst)[4]) {
         const int k = kt * GB_BK + lseg * 16;
         int tap = 0, kc = k;
         if (p.taps == 3) { tap = k / p.Kc; kc = k - tap * p.Kc; }
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             src = (long)m + tap - 1;
         }
         fulla = (k + 16 <= p.K);
-        load16(p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0), fulla, ra);
+        load16(p.X + (ok ? src : 0) * p.ldx + (ok ? kc : 0), fulla, dst);
         oka = ok;
     };
     // TAP3: chunk kc of the centre rows (LDS rows 1..128) and, threads 0..3, of the two halo rows (LDS rows 0 and 129)
@@ -610,11 +615,58 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
                 mma_tile(tap);                           // output row j of tap t reads X row j + t - 1 = LDS row j + t
             }
         }
+    } else if constexpr (PIPE) {
+        // KT K-tiles (32 columns each) per step and buffer.  KT = 2 (to amortise the ~1.1 us issue-to-landing time of an LDS-DMA piece,
+        // MI355X_MICROARCH.md) measured the same as KT = 1 (B = 1 forward 1.166 vs 1.157 ms, K = 520 layer 32 us either way): with four
+        // waves on one CU a 128 x 128 x 32 tile step is bound by its own split + 24 MFMAs per wave (~1.2 us), not by the transport.
+        // KT = 1 keeps the footprint at 74 KB.  The tiles are multiplied in K order as in the single-buffer kernel.
+        constexpr int KT = 1;
+        char* const base = smem;
+        auto use = [&](int bufi, int j) { sA = base + (bufi * KT + j) * Cfg::LDS_BYTES; sB = sA + Cfg::A_BYTES; };
+        f32x4 rq[KT][4];
+        bool okq[KT], fullq[KT];
+        auto stage = [&](int kt0, int bufi) {            // request the tiles kt0 .. kt0 + KT - 1 (W by LDS-DMA, X into registers)
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+                if (kt0 + j < nk) {
+                    use(bufi, j);
+                    dma_b(kt0 + j);
+                    gload(kt0 + j, rq[j]);                // (straight into this tile's registers: they are valid only after commit's wait)
+                    okq[j] = oka; fullq[j] = fulla;
+                }
+        };
+        auto commit = [&](int kt0, int bufi) {           // the X rows have arrived: split them into the buffer
+            if constexpr (KT == 2)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[0][2]), "+v"(rq[0][3]), "+v"(rq[1][0]), "+v"(rq[1][1]), "+v"(rq[1][2]), "+v"(rq[1][3]) : : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rq[0][0]), "+v"(rq[0][1]), "+v"(rq[0][2]), "+v"(rq[0][3]) : : "memory");
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+                if (kt0 + j < nk) {
+                    use(bufi, j);
+                    fulla = fullq[j];
+                    swrite_row(rq[j], okq[j], lrow, xs);
+                }
+            __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+        };
+        stage(0, 0);
+        commit(0, 0);
+        int bufi = 0;
+        for (int kt = 0; kt < nk; kt += KT, bufi ^= 1) {
+            __builtin_amdgcn_s_barrier();                // buffer `bufi` is complete; nobody reads the other one any more
+            const bool more = kt + KT < nk;
+            if (more) stage(kt + KT, bufi ^ 1);
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+                if (kt + j < nk) { use(bufi, j); mma_tile(0); }
+            if (more) commit(kt + KT, bufi ^ 1);
+        }
+        __builtin_amdgcn_s_barrier();                    // the epilogue reuses LDS (row-max reduction)
     } else {
         for (int kt = 0; kt < nk; ++kt) {
             if (kt) __builtin_amdgcn_s_barrier();        // everyone finished reading the previous tile
             dma_b(kt);
-            gload(kt);
+            gload(kt, ra);
             wait_all();
             swrite_row(ra, oka, lrow, xs);
             __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
@@ -638,10 +690,26 @@ int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
 }
 
 template <int NS>
+constexpr int go_pipe_lds() { return 2 * GOCfg<NS, false>::LDS_BYTES; }
+
+template <int NS>
+int launch_go_pipe(const GemmBP& p, const char* Ws, hipStream_t st) {
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, go_pipe_lds<NS>())););
+    gemm_nt_bf16_occ_kernel<NS, false, true><<<p.nblk, GO_THREADS, go_pipe_lds<NS>(), st>>>(p, Ws);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+template <int NS>
 int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
     static const bool no_tap3 = getenv("EV2H_GEMM_NO_TAP3") != nullptr;       // A/B switch
     if (p.taps == 3 && !no_tap3 && p.Kc % GB_BK == 0 && p.rows_per_seq % GB_BM == 0 && p.M % p.rows_per_seq == 0)
         return launch_go_t<NS, true>(p, Ws, st);
+    static const bool no_pipe = getenv("EV2H_GEMM_NO_PIPE") != nullptr;       // A/B switch
+    if (p.nblk <= 128 && !no_pipe) return launch_go_pipe<NS>(p, Ws, st);      // fewer workgroups than CUs: hide the K-step chain inside the workgroup
     return launch_go_t<NS, false>(p, Ws, st);
 }
 

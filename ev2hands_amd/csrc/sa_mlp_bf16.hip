@@ -47,6 +47,11 @@ struct SaBP {
     // not needed at all -- the neighbour's raw feature row feat[b][idx][0..nfeat) (nfeat <= 5, row stride ldf floats) and its
     // relative xyz are contracted with [W1f | W1x | b1] directly (W1f [C1][ldw1f], b1 [C1]); feat == NULL: P1 is the table.
     const float* feat; int ldf; const float* W1f; int ldw1f; const float* b1; int nfeat;
+    // streamed set abstraction, small grids: spg > 1 = the K / 32 strips of a group are spread over spg waves of one workgroup (a
+    // workgroup then holds 8 / spg groups) and their partial maxima are combined through LDS -- a max is exact and order-free, so
+    // the result is bit-identical; the weights are streamed once per strip SET instead of once per strip of the longest group.
+    // One window at a time (demo.py:24-33) has 16 workgroups for 256 CUs in the 128-centroid modules: 88 -> ~25 us per launch.
+    int spg;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -203,7 +208,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // the algorithmic HBM traffic: 32 windows in flight per XCD do not fit the 4 MB L2)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nbx = p.nblk >> 3;
     const int g_end = RES ? min(ngroups, (xcd + 1) * p.per_xcd) : ngroups;
-  for (int g = (RES ? xcd * p.per_xcd + slot * WV : L * WV) + wave; RES ? g < g_end : true; g += nbx * WV) {
+  const int spg = (RES || ROWS) ? 1 : max(1, __builtin_amdgcn_readfirstlane(p.spg)), sw = wave % spg;      // sw: this wave's strip of its group
+  for (int g = (RES ? xcd * p.per_xcd + slot * WV : (spg > 1 ? L * (WV / spg) + wave / spg : L * WV)) + wave * (RES || spg == 1); RES ? g < g_end : true;
+       g += nbx * WV) {
     const bool valid = g < ngroups;
     const int gg = valid ? g : ngroups - 1;
     const int b = gg / p.S;
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 
     float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* gi = nullptr;
-    if constexpr (!ROWS) { ctr = p.ctr4[gg]; gi = p.gidx + (size_t)gg * p.K; }
+    if constexpr (!ROWS) { ctr = p.ctr4[gg]; gi = p.gidx + (size_t)gg * p.K + sw * 32; }
     const int row0 = ROWS ? (gg - b * p.S) * 32 : 0;          // ROWS: first point of this strip inside its window
     float b3r[ROWS ? T3 : 1];
     if constexpr (ROWS) {
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // workgroup's longest group (DMA pieces and barriers), without computing.
     int my_strips = ROWS ? 1 : p.K >> 5;
     if (!ROWS && p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
+    if (spg > 1) my_strips = (valid && sw < my_strips) ? 1 : 0;      // spread: this wave owns strip sw of its group (or nothing)
     int nstrips = my_strips;
     if constexpr (!RES && !ROWS) {
         int* s_strips = reinterpret_cast<int*>(smem + WBYTES + Cfg::W1B + T2 * 32 * 4);
@@ -692,11 +700,31 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         STAMP(37);
     }
 
+    if constexpr (!ROWS && !RES) {
+        if (spg > 1) {
+            // combine the strips' partial maxima: [wave][C3] floats in the (now idle) tile buffer; the group's first wave finishes
+            float* smax = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int u = 0; u < T3; ++u) {
+                const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
+                if (half == 0) smax[wave * C3 + 32 * u + l31] = v;
+            }
+            __syncthreads();
+            if (sw == 0) {
+#pragma unroll
+                for (int u = 0; u < T3; ++u) {
+                    float v = smax[wave * C3 + 32 * u + l31];
+                    for (int k = 1; k < spg; ++k) v = fmaxf(v, smax[(wave + k) * C3 + 32 * u + l31]);
+                    mrun[u] = v;
+                }
+            }
+        }
+    }
     if constexpr (!ROWS) {
 #pragma unroll
         for (int u = 0; u < T3; ++u) {
             const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
-            if (valid && half == 0) {
+            if (valid && half == 0 && sw == 0) {
                 const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
                 p.out[(size_t)g * p.ldo + 32 * u + l31] = o;
                 am = max(am, __float_as_uint(o));
@@ -743,6 +771,17 @@ int launch_sab(SaBP p, hipStream_t st) {
     EV2H_ONCE_PER_DEVICE(attr_set,
         EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
+    {
+        // small grids (a few windows at a time): spread a group's strips over the waves of a workgroup (SaBP::spg).  Chosen by the
+        // launch size only -- the result does not depend on it.  EV2H_SA_NO_SPREAD=1: A/B switch.
+        static const bool no_spread = getenv("EV2H_SA_NO_SPREAD") != nullptr;
+        const int spg = p.K / 32;
+        p.spg = 1;
+        if (!no_spread && (spg == 2 || spg == 4) && p.nblk < 256 && SAB_WAVES * C3 * 4 <= 2 * Cfg::TILE) {
+            p.spg = spg;
+            p.nblk = ceil_div(p.B * p.S, SAB_WAVES / spg);
+        }
+    }
     sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
