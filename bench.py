@@ -84,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the two-stream / gather self-checks after the timed region")
+    ap.add_argument("--no-second-site", action="store_true", help="skip the short extra run that brackets the second-largest launch (roofline_second)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live HBM-traffic measurement (two rocprofv3 PMC passes of a 3-step child run of this script)")
     ap.add_argument("--collision", action="store_true",
@@ -232,7 +233,7 @@ def live_pmc_traffic(a, timeout_s=300):
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     nsteps = 3
-    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck",
+    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site",
              "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud]
     tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
@@ -503,7 +504,7 @@ def run_rank(a) -> int:
         L.ev2h_profile_set(None, None, None, 0)
     main_kernel_ms = ev.elapsed_ms(a.steps) if ev is not None else []
     second_kernel_ms = []
-    if L is not None:                      # the second-largest launch, bracketed in a short run of its own (outside `value`)
+    if L is not None and not a.no_second_site:     # the second-largest launch, bracketed in a short run of its own (outside `value`)
         k2 = max(3, min(a.steps // 4, 20))
         ev2 = HipEvents(k2)
         L.ev2h_profile_set(site2["tag"].encode(), ev2.start, ev2.stop, ev2.n)

@@ -269,10 +269,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const bool dbgw = (blockIdx.x == 300 && tid == 0);
     const int dbg_strip = nstrips > 1 ? 1 : 0;
 #endif
-    // XPF (BF16 set abstraction): the neighbour gather of strip s + 1 -- index, then coordinates and feature row (or the first
+    // XPF (set abstraction): the neighbour gather of strip s + 1 -- index, then coordinates and feature row (or the first
     // table chunk) -- is requested DURING strip s, so that a strip no longer starts with two dependent global-memory latencies
     // (index -> row: 6 of the 28 us of a strip in the phase timeline, with one workgroup per CU and nothing else to run)
-    constexpr bool XPF = L1M;
+    // (F16X2 and BF16: +0.9 % on the f16x2 step, dominant kernel 1.620 -> 1.576 ms, same-box build A/B profiles/r4_ab_xpf.txt;
+    // BF16X3 would spill: its widest instantiation already sits at 256 registers.)  EV2H_BUILD_DEFS=-DEV2H_NO_XPF: build without.
+#ifdef EV2H_NO_XPF
+    constexpr bool XPF = false;
+#else
+    constexpr bool XPF = !ROWS && NS <= 2;
+#endif
     f32x4 raw[4];                 // a lane's 16 gathered layer-1 values of the current chunk (XPF: survives into the next strip)
     int idx_cur = 0, idx_nxt = 0;
     float4 q_cur = make_float4(0.f, 0.f, 0.f, 0.f), f0_cur = q_cur, f1_cur = q_cur;
@@ -371,8 +377,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 }
             } else {
                 prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+                if (!XPF || strip == 0) {
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+                    for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+                }
             }
         }
         // BF16 set abstraction: layer 1 of chunk c as one MFMA (C = the table row in table mode)
@@ -544,7 +552,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_nxt) * p.ldf);
                     f0_cur = fr[0]; f1_cur = fr[1];
                 } else {
-                    const float4* pn = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx_nxt) * p.ldp);
+                    const float4* pn = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx_nxt) * p.ldp + HOFF * half);
 #pragma unroll
                     for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(pn + qi(j4));
                 }

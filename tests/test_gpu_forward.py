@@ -572,7 +572,8 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
 # switch re-associates sums (the un-fused / un-folded forms), selections and argmax identical in every case.
 AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_EXTRA_OVERLAP", "0", True), ("EV2H_COORD_OVERLAP", "0", True), ("EV2H_SA_NO_SKIP", "1", True), ("EV2H_SA_STREAMED", "1", True),
                ("EV2H_NO_TABLE_KERNEL", "1", False), ("EV2H_GEMM_NO_TAP3", "1", True), ("EV2H_NO_SKINNY_KERNEL", "1", False),
-               ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFOLDED", "1", False)]
+               ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFOLDED", "1", False),
+               ("EV2H_SA_NO_SPREAD", "1", True), ("EV2H_GEMM_NO_PIPE", "1", True)]
 
 _AB_SCRIPT = """
 import os, sys, torch
@@ -627,3 +628,26 @@ def test_ab_switch_paths_agree_with_the_default(ab_default, tmp_path, name, valu
             else:
                 assert rel(g, w) < 1e-5, (name, prec, k, rel(g, w))
         assert torch.equal(got[prec]["logits"].argmax(1), want[prec]["logits"].argmax(1)), (name, prec)
+
+
+def test_bf16_table_switch_agrees_with_the_table_free_layer1(tmp_path):
+    """EV2H_BF16_TABLE=1 (layer-1 tables + gathers, as in the other modes) against the default BF16 path (layer 1 on the matrix pipe
+    from the raw feature rows): same selections, outputs within bf16 rounding of each other, both inside the bf16 bar against the
+    oracle (test_bf16_mode_against_the_oracle runs the default)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    script.write_text(_AB_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).replace("('f16x2', 'bf16x3')", "('bf16',)"))
+    res = {}
+    for tag, env in (("mfma", {}), ("table", {"EV2H_BF16_TABLE": "1"})):
+        out = tmp_path / f"{tag}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)["bf16"]
+    for k in ("gidx", "nn"):
+        assert torch.equal(res["mfma"][k], res["table"][k]), k
+    worst = max(rel(res["mfma"][k], res["table"][k]) for k in res["mfma"] if k not in ("gidx", "nn"))
+    agree = float((res["mfma"]["logits"].argmax(1) == res["table"]["logits"].argmax(1)).float().mean())
+    print(f"bf16: table-free layer 1 vs layer-1 tables: worst relative difference {worst:.2e}, argmax agreement {agree:.4f}")
+    assert worst < 3e-2 and agree > 0.97

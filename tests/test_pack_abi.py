@@ -153,3 +153,27 @@ def test_weight_spread_report():
     nz, lo, hi = tot(pack.PackedWeights(sd, "cpu", 4, "f16x2", equalize=False))
     assert lo > 0.5 * nz and hi > 0.3 * nz
     assert pack.PackedWeights(sd, "cpu", 4, "bf16x3").weight_spread() == {}                      # f16x2 only
+
+
+def test_integration_md_binding_stub():
+    """The ctypes stub INTEGRATION.md section 2 shows for ev2h_pack_weights, executed as written (plus EV2H_PACK_HOST_ONLY: no GPU
+    here) on a DataParallel-style checkpoint."""
+    L = C.CDLL(_lib.LIB_PATH)
+    L.ev2h_last_error.restype = C.c_char_p
+
+    class TensorDesc(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int), ("ndim", C.c_int), ("shape", C.c_int64 * 4)]
+    sd = {"module." + k: v for k, v in synth.synth_state_dict(5, 1).items()}
+    keep = [(k.encode(), v.numpy()) for k, v in sd.items() if v.dtype == torch.float32]
+    descs = (TensorDesc * len(keep))()
+    for d, (k, a) in zip(descs, keep):
+        d.name, d.data, d.dtype, d.ndim = k, a.ctypes.data, 0, a.ndim
+        d.shape[:a.ndim] = a.shape
+    handle = C.c_void_p()
+    EQUALIZE, HOST_ONLY, F16X2 = 1, 2, 2
+    assert L.ev2h_pack_weights(descs, len(descs), 5, F16X2, EQUALIZE | HOST_ONLY, C.byref(handle)) == 0, L.ev2h_last_error()
+    L.ev2h_packed_weights.restype = C.c_void_p
+    w = _lib.Weights.from_address(L.ev2h_packed_weights(handle))
+    assert w.precision == 2 and w.flags == _lib.W_EQUALIZED and w.sa1.nbranch == 3 and w.qconv0.O == 512
+    L.ev2h_packed_free.argtypes = [C.c_void_p]
+    L.ev2h_packed_free(handle)
