@@ -324,13 +324,14 @@ static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, i
 // from the feature rows (ev2h_sa_desc.feat) -- no layer-1 table is computed, written (1.46 GB per 256-window step) or gathered.
 // EV2H_BF16_TABLE=1: A/B switch back to the table.
 static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
-    static const bool table = getenv("EV2H_BF16_TABLE") != nullptr;
-    return precision == EV2H_PREC_BF16 && m.kf == 8 && !table;
+    static const bool table = getenv("EV2H_BF16_TABLE") != nullptr || getenv("EV2H_L1_TABLE") != nullptr;
+    return (precision == EV2H_PREC_BF16 || precision == EV2H_PREC_F16X2) && m.kf == 8 && !table;
 }
 
 static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,
                        const int32_t* cnt, int B, int Npts, const float* P1, float* out, int ldo, ev2h_stream_t st, bool ranges,
-                       const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax, const float* feat = nullptr, int nfeat = 0) {
+                       const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax, const float* feat = nullptr, int nfeat = 0,
+                       const uint32_t* feat_amax = nullptr) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     int coff1 = 0, coff3 = 0;
@@ -342,11 +343,15 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
-        if (feat && bf16_direct_layer1(precision, m)) {
+        const bool direct = feat && bf16_direct_layer1(precision, m);
+        if (direct) {
             d.feat = feat; d.ldf = 8; d.W1f = m.W1f + (size_t)coff1 * m.kf; d.ldw1f = m.kf; d.b1 = m.b1 + coff1; d.nfeat = nfeat;
+            d.w1_unscale = br.w1_unscale;
+            if (ranges) { d.feat_amax = feat_amax; d.w1f_norm = m.w1f_norm; d.b1_max = m.b1_max; }
         }
         if (ranges) {
-            d.p1_scale = p1_scale; d.p1_amax = p1_amax; d.out_amax = out_amax;
+            if (!direct) { d.p1_scale = p1_scale; d.p1_amax = p1_amax; }
+            d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
         }
         static const bool no_skip = getenv("EV2H_SA_NO_SKIP") != nullptr;       // A/B switch: process padding strips too
@@ -367,7 +372,7 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
                      const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax, int nfeat = 0) {
     if (!bf16_direct_layer1(precision, m)) RUN(sa_table(precision, m, feat, ldf, B, Npts, P1, st, feat_amax, p1_amax, p1_scale));
     return sa_branches(precision, tag, m, pts4, ctr4, gidx, cnt, B, Npts, P1, out, ldo, st, feat_amax != nullptr, p1_amax, p1_scale, out_amax,
-                       ldf == 8 ? feat : nullptr, nfeat);
+                       ldf == 8 ? feat : nullptr, nfeat, feat_amax);
 }
 
 }  // namespace
@@ -575,7 +580,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
         RUN(sa_branches(prec, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
-                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C));
+                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C, ws.r(R_FEAT)));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {

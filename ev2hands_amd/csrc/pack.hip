@@ -629,6 +629,7 @@ struct Builder {
             vec(&br.b3, n + ".b3", L2.b);
             br.C1 = C1; br.C2 = C2; br.C3 = C3; br.K = sp.nsample[i]; br.radius = sp.radius[i];
             br.w1x_norm = bound(max_row_l1(&L0.W[nfeat], C1, 3, L0.I));
+            br.w1_unscale = (float)plane_unscale(L0.W.data(), L0.W.size(), ns);      // [W1f | W1x] of this branch: the layer-1 MFMA of the F16X2 feature mode
             br.w2_norm = bound(max_row_l1(L1.W.data(), C2, C1, C1));
             br.b2_max = bound(max_abs(L1.b));
             if (ns) chain_images(br, n, L1.W.data(), L2.W.data(), C1, C2, C3);

@@ -47,6 +47,9 @@ struct SaBP {
     // not needed at all -- the neighbour's raw feature row feat[b][idx][0..nfeat) (nfeat <= 5, row stride ldf floats) and its
     // relative xyz are contracted with [W1f | W1x | b1] directly (W1f [C1][ldw1f], b1 [C1]); feat == NULL: P1 is the table.
     const float* feat; int ldf; const float* W1f; int ldw1f; const float* b1; int nfeat;
+    // F16X2 with raw feature rows: range record of the feature rows, the layer-1 bounds and the power-of-two plane factor of
+    // [W1f | W1x] (ev2h_sa_desc)
+    const unsigned* feat_amax; float w1f_norm, b1_max, u1;
     // streamed set abstraction, small grids: spg > 1 = the K / 32 strips of a group are spread over spg waves of one workgroup (a
     // workgroup then holds 8 / spg groups) and their partial maxima are combined through LDS -- a max is exact and order-free, so
     // the result is bit-identical; the weights are streamed once per strip SET instead of once per strip of the longest group.
@@ -80,7 +83,9 @@ struct SaBCfg {
     // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
     // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
     static constexpr int SB2W = (NS == 2) ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
-    static constexpr int W1B = (NS == 1) ? C1 * 32 : C1 * 16;        // W1x in fp32 (12 B per channel, padded), or -- BF16 -- the layer-1 A tile [C1][16 k] in bf16
+    // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
+    // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
+    static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 16;
     static constexpr int SMALL = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
     static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
@@ -129,6 +134,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // of a lane are channels 8q + 4 half + e, so the layer-2 k slot (block m, half h, e) is channel 16m + 4h + (e & 3) + 8(e >> 2):
     // the BF16 W2 images are stored in that order (ev2h_tile_geometry out[9] = 1), for every kernel mode.
     constexpr bool L1M = (NS == 1) && !ROWS;
+    // F16X2, set abstraction with RAW FEATURE ROWS (ev2h_sa_desc.feat): layer 1 on the matrix pipe with a power-of-two scale PER
+    // NEIGHBOUR.  The 8 inputs v = (f0..f4, dx, dy, dz) of neighbour j are multiplied by s_j (their maximum -> [2^14, 2^15)) and split
+    // into fp16 planes; B1 = [xh(8) | xl(8)], A = [wh | wh] and [wl | 0] (planes of [W1f | W1x] / u1): two MFMAs per 32-channel chunk
+    // give the three plane products, and since the neighbour is the N index of the product its column is un-scaled per LANE:
+    // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1).  A neighbour's inputs keep 22 bits relative to ITS OWN largest input -- a 1e7-event
+    // hot pixel no longer sets the scale of the other neighbours, which is what the exact fp32 layer 1 used to guarantee -- no
+    // layer-1 table is computed, stored or gathered (48 B instead of 512 B per neighbour), and one fma replaces three.
+    constexpr bool L1F = (NS == 2) && !ROWS;
 #ifdef EV2H_FRAG_PIPE_ALL
     constexpr bool FRAG_PIPE = true;
 #else
@@ -149,6 +162,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int half = lane >> 5, l31 = lane & 31;
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
+    const bool fmode = L1F && p.feat != nullptr;               // (uniform)
+    float* sb1w = reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1;      // F16X2 feature mode: s1 b1 of this wave's window
 
     if constexpr (L1M) {
         // A1 [C1][16 k] bf16 (one 32-byte row per channel), k slots as listed above
@@ -169,10 +184,30 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j = 0; j < 8; ++j) { unsigned o[1]; split_planes<1>(k[2 * j], k[2 * j + 1], o); d[j] = o[0]; }
         }
     } else if constexpr (!ROWS) {
-        for (int i = tid; i < C1; i += WV * 64) {
-            const float4 w = p.W1x[i];
-            float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
-            d[0] = w.x; d[4] = w.y; d[8] = w.z;
+        if (fmode) {
+            // A tiles of layer 1: row i = [wh(v0..v7) | wh(v0..v7)] then [wl(v0..v7) | 0], v = (f0..f4, dx, dy, dz), planes of W / u1
+            const float iu = 1.f / p.u1;                          // (power of two: exact)
+            for (int i = tid; i < C1; i += WV * 64) {
+                const float4 w = p.W1x[i];
+                float k[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) k[j] = 0.f;
+                for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iu;
+                k[5] = w.x * iu; k[6] = w.y * iu; k[7] = w.z * iu;
+                unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned o[NS > 1 ? NS : 2];
+                    if constexpr (NS == 2) split_planes<2>(k[2 * j], k[2 * j + 1], o);
+                    d[j] = o[0]; d[4 + j] = o[0]; d[8 + j] = o[1]; d[12 + j] = 0u;
+                }
+            }
+        } else {
+            for (int i = tid; i < C1; i += WV * 64) {
+                const float4 w = p.W1x[i];
+                float* d = reinterpret_cast<float*>(sW1xT) + (i >> 2) * 12 + (i & 3);
+                d[0] = w.x; d[4] = w.y; d[8] = w.z;
+            }
         }
     }
     for (int i = tid; i < T2 * 32; i += WV * 64) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
@@ -233,7 +268,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
     float s1 = 1.f, c2 = p.u2, c3 = p.u3;
     if constexpr (NS == 2) {
-        if (p.p1_amax) {
+        if (fmode && p.feat_amax) {
+            // no table and no producer that chose s1: the same bound, evaluated here from the record of the feature rows
+            const float bnd = __fmaf_rn(p.w1f_norm, __uint_as_float(p.feat_amax[b]), p.b1_max) + p.w1x_norm * p.dmax;
+            s1 = f16x2_scale(__float_as_uint(bnd));
+            const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bnd, p.b2_max)));
+            c2 = p.u2 * s2 * pow2_inverse(s1);
+            c3 = p.u3 * pow2_inverse(s2);
+        } else if (!fmode && p.p1_amax) {
             float a1 = __uint_as_float(p.p1_amax[b]);
             if constexpr (DIRECT) { s1 = f16x2_scale(p.p1_amax[b]); a1 *= s1; }       // unscaled input rows: scaled as they are read
             else s1 = p.p1_scale[b];
@@ -248,6 +290,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c2)));
         c3 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c3)));
         for (int i = lane; i < T2 * 32; i += 64) sbw[i] = sb2[i] * s1;           // read back by this wave only (LDS ops of a wave stay in order)
+        if constexpr (L1F) {
+            if (fmode) for (int i = lane; i < C1; i += 64) sb1w[i] = p.b1[i] * s1;
+        }
     }
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
@@ -308,14 +353,15 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
         }
         float dx = 0.f, dy = 0.f, dz = 0.f;
-        // a lane's j4-th float4 of a 32-channel chunk: channels 16 half + 4 j4 + (0..3), or -- BF16 -- 8 j4 + 4 half + (0..3) (the D
-        // layout of the layer-1 MFMA; row bases then carry no half offset)
-        auto qi = [&](int j4) { return NS == 1 ? 2 * j4 + half : j4; };
-        constexpr int HOFF = NS == 1 ? 0 : 16;
+        // a lane's j4-th float4 of a 32-channel chunk: channels 8 j4 + 4 half + (0..3) -- the D layout of a 32 x 32 MFMA, so that layer 1
+        // may come from the matrix pipe (BF16, F16X2 feature mode) or from the VALU without changing the W2 images (W2PERM)
+        auto qi = [&](int j4) { return 2 * j4 + half; };
+        constexpr int HOFF = 0;
         const float4* prow = nullptr;
         const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
         float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
-        u32x4 b1f = {0u, 0u, 0u, 0u};                      // L1M: the B operand of the layer-1 MFMA
+        u32x4 b1f = {0u, 0u, 0u, 0u};                      // L1M / L1F: the B operand of the layer-1 MFMA
+        float cj = 1.f;                                    // L1F: u1 s1 / s_j of this lane's neighbour
         // ROWS: raw = (w0 T0 + w1 T1) + w2 T2 of chunk c (pointnet2_utils.py:303 applied to the layer-1 table; the table is stored
         // scaled by s1 in F16X2, so the blend is s1 H1 before the ReLU)
         f32x4 trw[ROWS ? 3 : 1][4];
@@ -351,8 +397,24 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             const float4 q = XPF ? q_cur : p.pts4[(size_t)b * p.Npts + idx];
             if constexpr (XPF) idx_nxt = (strip + 1 < my_strips) ? gi[(strip + 1) * 32 + l31] : idx_cur;
             dx = __fsub_rn(q.x, ctr.x); dy = __fsub_rn(q.y, ctr.y); dz = __fsub_rn(q.z, ctr.z);
-            if constexpr (NS == 2) { dx *= s1; dy *= s1; dz *= s1; }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
-            if constexpr (L1M) {
+            if constexpr (NS == 2) { if (!fmode) { dx *= s1; dy *= s1; dz *= s1; } }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
+            if (fmode) {
+                if constexpr (L1F) {
+                    // B1 = [xh(v0..v7) | xl(v0..v7)], v = (f0..f4, dx, dy, dz) of this lane's neighbour times its own power of two s_j
+                    float v[8] = {f0_cur.x, f0_cur.y, f0_cur.z, f0_cur.w, f1_cur.x, dx, dy, dz};
+                    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+#pragma unroll
+                    for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+                    const float sj = f16x2_scale(__float_as_uint(m));
+                    cj = (p.u1 * s1) * pow2_inverse(sj);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        unsigned o[2];
+                        split_planes<2>(v[2 * w] * sj, v[2 * w + 1] * sj, o);
+                        b1f[w] = half ? o[1] : o[0];
+                    }
+                }
+            } else if constexpr (L1M) {
                 // B1: this lane's 8 k slots of its neighbour (half 0: k 0..7, half 1: k 8..15), hi / lo bf16 planes of the inputs
                 float f[8];
 #pragma unroll
@@ -376,16 +438,25 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     b1f[w] = o[0];
                 }
             } else {
-                prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp + 16 * half);
+                prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp);
                 if (!XPF || strip == 0) {
 #pragma unroll
-                    for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + j4);
+                    for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + qi(j4));
                 }
             }
         }
-        // BF16 set abstraction: layer 1 of chunk c as one MFMA (C = the table row in table mode)
+        // layer 1 of chunk c on the matrix pipe.  BF16: one MFMA (C = the table row in table mode); F16X2 feature mode: the two
+        // products with [wl | 0] and [wh | wh]
         auto layer1 = [&](int c) {
             f32x16 acc;
+            if constexpr (L1F) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const char* ar = smem + WBYTES + (32 * c + l31) * 64 + half * 16;
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(ar), al = *reinterpret_cast<const u32x4*>(ar + 32);
+                acc = mfma_planes<2>(al, b1f, acc);
+                return mfma_planes<2>(ah, b1f, acc);
+            } else {
             if (p.feat) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -395,8 +466,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
             const u32x4 a1 = *reinterpret_cast<const u32x4*>(smem + WBYTES + (32 * c + l31) * 32 + half * 16);
             return mfma_planes<1>(a1, b1f, acc);
+            }
         };
         f32x16 d1;
+        if constexpr (L1F) { if (fmode) d1 = layer1(0); }
         if constexpr (L1M) {
             d1 = layer1(0);
             if (!p.feat && NC1 > 1) {
@@ -429,9 +502,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             if constexpr (!RES) {
                 if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
             }
-            if (!ROWS && !L1M && !Cfg::PREFETCH_P1 && c > 0) {
+            if (!ROWS && !L1M && !fmode && !Cfg::PREFETCH_P1 && c > 0) {
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + j4);
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + qi(j4));
             }
             // layer-1 finish in fp32, then split: lane's channels 32c + 16*half + [0,16) = k-slots of 2 MFMAs
             u32x4 bp[2][NS];
@@ -443,10 +516,26 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     split_planes<1>(d1[2 * w], d1[2 * w + 1], o);
                     bp[w >> 2][0][w & 3] = relu_pk_bf16(o[0]);
                 }
+            } else if (fmode) {
+                if constexpr (L1F) {
+                    // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1): D register 4q + e of a lane is channel 32c + 8q + 4 half + e
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
+                        unsigned lo[2], hi[2];
+                        split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q], cj, bv[0])), relu_sat_f16(__fmaf_rn(d1[4 * q + 1], cj, bv[1])), lo);
+                        split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q + 2], cj, bv[2])), relu_sat_f16(__fmaf_rn(d1[4 * q + 3], cj, bv[3])), hi);
+#pragma unroll
+                        for (int s_ = 0; s_ < 2; ++s_) {
+                            bp[q >> 1][s_][(q & 1) * 2 + 0] = lo[s_];
+                            bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
+                        }
+                    }
+                }
             } else {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
-                const f32x4* wp = sW1xT + (8 * c + 4 * half + j4) * 3;
+                const f32x4* wp = sW1xT + (8 * c + 2 * j4 + half) * 3;
                 const f32x4 wx = wp[0], wy = wp[1], wz = wp[2];
                 f32x4 v;
 #pragma unroll
@@ -476,9 +565,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
             if constexpr (ROWS) {
                 if (c + 1 < NC1) fetch(c + 1);      // in flight under this chunk's MFMAs, blended after them
-            } else if (!L1M && Cfg::PREFETCH_P1 && c + 1 < NC1) {
+            } else if (!L1M && !fmode && Cfg::PREFETCH_P1 && c + 1 < NC1) {
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + j4);
+                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + qi(j4));
             }
             STAMP(3 + 4 * c);
             const char* pa = cur + l31 * RS2 + (16 * half) * 2;
@@ -520,6 +609,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
             if constexpr (ROWS) {
                 if (c + 1 < NC1) blend();
+            }
+            if constexpr (L1F) {
+                if (fmode && c + 1 < NC1) d1 = layer1(c + 1);
             }
             if constexpr (L1M) {
                 // next chunk's layer 1: issued behind this chunk's MFMAs, converted at the top of the next iteration; its table row
@@ -842,7 +934,7 @@ int fill_geometry(int out[10]) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     out[0] = Cfg::T2; out[1] = Cfg::C2P; out[2] = Cfg::RS2; out[3] = Cfg::RS3; out[4] = Cfg::TB2; out[5] = Cfg::TB3;
     out[8] = Cfg::PACK4 ? Cfg::REM : 0;
-    out[9] = NS == 1 ? 1 : 0;          // BF16: the W2 images hold their k slots in the layer-1 D-register order (see L1M in the kernel)
+    out[9] = 1;                        // the W2 images hold their k slots in the D-register order of a 32 x 32 MFMA (see qi / L1M / L1F in the kernel)
     return EV2H_OK;
 }
 template <int NS>
@@ -908,9 +1000,15 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     if (d->feat) {
-        EV2H_CHECK_ARG(d->precision == EV2H_PREC_BF16 && d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 && d->ldf >= 8 && (d->ldf % 4) == 0 &&
-                       d->ldw1f >= d->nfeat);
+        EV2H_CHECK_ARG((d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_F16X2) && d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 &&
+                       d->ldf >= 8 && (d->ldf % 4) == 0 && d->ldw1f >= d->nfeat);
         p.feat = d->feat; p.ldf = d->ldf; p.W1f = d->W1f; p.ldw1f = d->ldw1f; p.b1 = d->b1; p.nfeat = d->nfeat;
+        p.u1 = d->w1_unscale > 0.f ? d->w1_unscale : 1.f;
+        if (d->precision == EV2H_PREC_F16X2 && d->feat_amax) {
+            EV2H_CHECK_ARG(d->dmax > 0.f && d->w1f_norm >= 0.f && d->b1_max >= 0.f && d->w1x_norm >= 0.f && d->w2_norm >= 0.f && d->b2_max >= 0.f);
+            p.feat_amax = d->feat_amax; p.w1f_norm = d->w1f_norm; p.b1_max = d->b1_max;
+            p.w1x_norm = d->w1x_norm; p.dmax = d->dmax; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
+        }
     } else {
         EV2H_CHECK_ARG(d->P1 != nullptr);
     }

@@ -136,15 +136,15 @@ def make_w_image(W: torch.Tensor, precision: str, rows: int = 128):
 
 
 def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: str = "f32", cnt=None,
-               p1_scale=None, p1_amax=None, dmax: float = 0.0, out_amax=None, feat=None, W1f=None, b1=None) -> torch.Tensor:
+               p1_scale=None, p1_amax=None, dmax: float = 0.0, out_amax=None, feat=None, W1f=None, b1=None, feat_amax=None) -> torch.Tensor:
     """Fused grouped MLP + max (ev2h_sa_mlp_max).  P1 [B,Npts,C1], gidx [B,S,K] int32 -> [B,S,C3].
     W2 [roundup(C2,32), C1], W3 [C3, roundup(C2,8)] fp32 (padded); 16-bit tile images are built here when needed.
     cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped.
     p1_scale [B] float32 / p1_amax [B] range record / dmax / out_amax: the F16X2 range arguments of ev2h_sa_desc (P1 then
     holds p1_scale[b] * table)."""
     if feat is not None:
-        # "bf16" only: layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
-        # b1 [C1] -- no table (P1 may be None)
+        # "bf16" / "f16x2": layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
+        # b1 [C1] -- no table (P1 may be None); feat_amax [B] range record of the rows + dmax: F16X2 range handling
         B, Npts, C1 = feat.shape[0], feat.shape[1], W1x.shape[0]
         dev = feat.device
     else:
@@ -158,6 +158,15 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     if feat is not None:
         W1fc, b1c = W1f.contiguous(), b1.contiguous()
         d.feat, d.ldf, d.W1f, d.ldw1f, d.b1, d.nfeat = feat.data_ptr(), feat.shape[2], W1fc.data_ptr(), W1fc.shape[1], b1c.data_ptr(), W1fc.shape[1]
+        if precision == "f16x2":
+            from .pack import NS_OF, plane_unscale
+            d.w1_unscale = plane_unscale(torch.cat([W1fc, W1x[:, :3]], 1).detach().cpu().double().numpy(), NS_OF[precision])
+            if feat_amax is not None:            # F16X2 range handling of the feature mode (ev2h_sa_desc.feat_amax)
+                d.feat_amax, d.dmax = feat_amax.data_ptr(), dmax
+                d.w1f_norm, d.b1_max = float(W1fc.abs().sum(1).max()) * (1 + 1e-6), float(b1c.abs().max()) * (1 + 1e-6)
+                d.w1x_norm = float(W1x[:, :3].abs().sum(1).max()) * (1 + 1e-6)
+                d.w2_norm = float(W2[:C2].abs().sum(1).max()) * (1 + 1e-6)
+                d.b2_max = float(b2[:C2].abs().max()) * (1 + 1e-6)
     d.W1x, d.W2, d.b2, d.W3, d.b3 = W1x.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr()
     d.out, d.ldo = out.data_ptr(), C3
     d.B, d.Npts, d.S, d.K, d.C1, d.C2, d.C3 = B, Npts, S, K, C1, C2, C3

@@ -180,7 +180,7 @@ def test_tile_geometry_comes_from_the_kernels(built):
     from ev2hands_amd import pack
     out = (C.c_int * 10)()
     assert built.ev2h_tile_geometry(128, 196, 256, 2, out) == 0
-    assert list(out) == [7, 208, 144, 848, 7 * 32 * 144, 32 * 848, 144, 32, 4, 0]     # 4 leftover channels share MFMAs (f16x2 only)
+    assert list(out) == [7, 208, 144, 848, 7 * 32 * 144, 32 * 848, 144, 32, 4, 1]     # 4 leftover channels share MFMAs (f16x2 only); W2 k slots in D-register order
     assert built.ev2h_tile_geometry(128, 196, 256, 3, out) == 0 and out[8] == 0
     assert built.ev2h_tile_geometry(100, 100, 100, 2, out) != 0 and b"unsupported chain" in built.ev2h_last_error()
     rng = np.random.default_rng(0)
