@@ -50,9 +50,10 @@ typedef void* ev2h_stream_t; /* hipStream_t */
  *          POINTS or between channels that only the data produces: ev2h_range_report counts, per tensor and window, the values
  *          that sit below 2^-17 of the maximum, and BF16X3 / F32 have no such limit;
  *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3).
- * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the K = 8
- * layer-1 tables of the raw cloud, the one-row-per-window layers (ev2h_gemm_desc.skinny) and the folded attention product
- * (ev2h_attn_sim_folded). */
+ * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the one-row-per-
+ * window layers (ev2h_gemm_desc.skinny), the folded attention product (ev2h_attn_sim_folded) and -- where they are still computed
+ * (F32, BF16X3; EV2H_L1_TABLE=1) -- the K = 8 layer-1 tables of the raw cloud.  In F16X2 and BF16 ev2h_forward runs layer 1 of the set
+ * abstractions that read raw feature rows on the matrix pipe (ev2h_sa_desc.feat), without a table. */
 #define EV2H_PREC_F32 0
 #define EV2H_PREC_BF16 1
 #define EV2H_PREC_F16X2 2
@@ -552,7 +553,7 @@ int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, i
 /* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in
  * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown.
  * "rng.<tensor>" (e.g. "rng.l0", "rng.p1b") = the F16X2 range record of that tensor, "p1scale" = the storage scales of the
- * four layer-1 tables [4][B] (enc.sa1, enc.sa2, left, right). */
+ * five layer-1 tables [5][B] (enc.sa1, enc.sa2, left, right, fp1; only enc.sa2 and fp1 are computed in the default F16X2 path). */
 const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);
 
 #ifdef __cplusplus
