@@ -90,6 +90,8 @@ def parse(argv=None):
     ap.add_argument("--collision", action="store_true",
                     help="BASELINE config 5: add the two-hand self-collision term to every step (pair search with the evaluation's "
                          "max_collisions = 8, then the intersection loss's pair search with 16 and its distance-field penalty)")
+    ap.add_argument("--collision-score", action="store_true",
+                    help="with --collision: also the evaluation script's collision count (a second pair search, cap 8) in every step")
     ap.add_argument("--collision-mesh", default="surface", choices=["surface", "soup"],
                     help="geometry of the synthetic hand assets for --collision: 'surface' = a mitten-shaped mesh with smooth blend shapes and "
                          "skinning (deforms like a hand mesh: tens to hundreds of colliding triangle pairs per window), 'soup' = the default "
@@ -438,9 +440,13 @@ def run_rank(a) -> int:
                 out = net.net(xyz, net.hands, rows=rows)
                 if closs is not None:
                     # device-side only: the face tables were uploaded in the set-up (a pageable host->device copy per call would
-                    # synchronise the stream six times per step); evaluate_ev2hands_r.py:128-160, losses.py:60-102
-                    out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], dev_faces[0], dev_faces[1],
-                                                                      max_per_triangle=8)
+                    # synchronise the stream six times per step).  BASELINE config 5 names the intersection-LOSS term (losses.py:60-102:
+                    # pair search with max_collisions = 16 + conic distance-field penalty); --collision-score adds the evaluation
+                    # script's count (evaluate_ev2hands_r.py:128-160: a second search with max_collisions = 8), which the reference
+                    # never runs in the same step
+                    if a.collision_score:
+                        out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], dev_faces[0], dev_faces[1],
+                                                                          max_per_triangle=8)
                     out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
                 return out
 
@@ -594,8 +600,9 @@ def run_rank(a) -> int:
             "dtype": "stub" if a.stub else DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
                                    f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
-                                   + (" + two-hand self-collision count (cap 8) and intersection penalty (cap 16, pair list sized 2 x 1538 x 16 per window: never "
-                                      "truncated) per window; hand meshes: " +
+                                   + (" + intersection-loss term per window (pair search cap 16, list sized 2 x 1538 x 16: never truncated; conic "
+                                      "distance-field penalty)" + (" + collision count for the score (second search, cap 8)" if a.collision_score else "") +
+                                      "; hand meshes: " +
                                       ("mitten-shaped surfaces with smooth skinning (tens to hundreds of colliding pairs per window)" if a.collision_mesh == "surface"
                                        else "random triangle soup (every mesh intersects itself ~24 000 times: worst case for the pair search)")
                                       if a.collision else ""),

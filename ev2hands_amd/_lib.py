@@ -33,7 +33,7 @@ class SaDesc(C.Structure):
                 ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci),
                 ("p1_scale", vp), ("p1_amax", vp), ("w1x_norm", C.c_float), ("dmax", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
                 ("out_amax", vp), ("feat", vp), ("ldf", ci), ("W1f", vp), ("ldw1f", ci), ("b1", vp), ("nfeat", ci),
-                ("feat_amax", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float), ("w1_unscale", C.c_float)]
+                ("feat_amax", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float), ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float)]
 
 
 class FpDesc(C.Structure):
@@ -48,7 +48,7 @@ class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_double), ("W2s", vp), ("W3s", vp),
                 ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("w1x_norm", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
-                ("w1_unscale", C.c_float)]
+                ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float)]
 
 
 class SaModule(C.Structure):

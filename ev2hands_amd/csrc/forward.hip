@@ -346,7 +346,7 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
         const bool direct = feat && bf16_direct_layer1(precision, m);
         if (direct) {
             d.feat = feat; d.ldf = 8; d.W1f = m.W1f + (size_t)coff1 * m.kf; d.ldw1f = m.kf; d.b1 = m.b1 + coff1; d.nfeat = nfeat;
-            d.w1_unscale = br.w1_unscale;
+            d.w1f_unscale = br.w1f_unscale; d.w1x_unscale = br.w1x_unscale;
             if (ranges) { d.feat_amax = feat_amax; d.w1f_norm = m.w1f_norm; d.b1_max = m.b1_max; }
         }
         if (ranges) {

@@ -629,7 +629,13 @@ struct Builder {
             vec(&br.b3, n + ".b3", L2.b);
             br.C1 = C1; br.C2 = C2; br.C3 = C3; br.K = sp.nsample[i]; br.radius = sp.radius[i];
             br.w1x_norm = bound(max_row_l1(&L0.W[nfeat], C1, 3, L0.I));
-            br.w1_unscale = (float)plane_unscale(L0.W.data(), L0.W.size(), ns);      // [W1f | W1x] of this branch: the layer-1 MFMA of the F16X2 feature mode
+            {   // plane factors of the two column blocks of this branch's layer 1 (the layer-1 MFMA of the F16X2 feature mode)
+                Vec wf((size_t)C1 * nfeat);
+                for (int r = 0; r < C1; ++r)
+                    for (int c = 0; c < nfeat; ++c) wf[(size_t)r * nfeat + c] = L0.W[(size_t)r * L0.I + c];
+                br.w1f_unscale = (float)plane_unscale(wf.data(), wf.size(), ns);
+                br.w1x_unscale = (float)plane_unscale(W1x.data(), W1x.size(), ns);
+            }
             br.w2_norm = bound(max_row_l1(L1.W.data(), C2, C1, C1));
             br.b2_max = bound(max_abs(L1.b));
             if (ns) chain_images(br, n, L1.W.data(), L2.W.data(), C1, C2, C3);

@@ -6,6 +6,7 @@
 // All discrete selections reproduce the reference's arithmetic forms exactly: squared norms as
 // (x*x + y*y) + z*z with separate roundings, matmul-form distances as fma chains in k order
 // (what MKL's K=3 sgemm produces), `d > r*r` in fp32, stable first-index tie breaks.
+#include <cstdlib>
 #include "common.hpp"
 #include "ev2hands_hip.h"
 
@@ -363,7 +364,11 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     }
     a.cnt = cnt;
     dim3 grid(ceil_div(S, BALL_CTR_PER_WG), B);
-    if (N > 8192) {
+    // Windows above EV2H_BALL_LDS_MAX points (default 2048: the reference's operating point keeps the LDS form, measured neutral there) read their points from L2 instead of staging them in LDS: at N = 8192 the
+    // 128 KB of staged points leave ONE 4-wave workgroup per CU, and the scan is latency-bound -- the L2 form is 3x faster there
+    // (1.74 -> ~0.5 ms per 128 windows; BASELINE config 5's shape +14.6 % windows/s, same-box A/B).  Same arithmetic, same results.
+    static const int lds_max = getenv("EV2H_BALL_LDS_MAX") ? atoi(getenv("EV2H_BALL_LDS_MAX")) : 2048;
+    if (N > 8192 || N > lds_max) {
         ball_query_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;

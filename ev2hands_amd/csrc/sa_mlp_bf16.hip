@@ -49,7 +49,7 @@ struct SaBP {
     const float* feat; int ldf; const float* W1f; int ldw1f; const float* b1; int nfeat;
     // F16X2 with raw feature rows: range record of the feature rows, the layer-1 bounds and the power-of-two plane factor of
     // [W1f | W1x] (ev2h_sa_desc)
-    const unsigned* feat_amax; float w1f_norm, b1_max, u1;
+    const unsigned* feat_amax; float w1f_norm, b1_max, u1f, u1x;
     // streamed set abstraction, small grids: spg > 1 = the K / 32 strips of a group are spread over spg waves of one workgroup (a
     // workgroup then holds 8 / spg groups) and their partial maxima are combined through LDS -- a max is exact and order-free, so
     // the result is bit-identical; the weights are streamed once per strip SET instead of once per strip of the longest group.
@@ -135,12 +135,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // the BF16 W2 images are stored in that order (ev2h_tile_geometry out[9] = 1), for every kernel mode.
     constexpr bool L1M = (NS == 1) && !ROWS;
     // F16X2, set abstraction with RAW FEATURE ROWS (ev2h_sa_desc.feat): layer 1 on the matrix pipe with a power-of-two scale PER
-    // NEIGHBOUR.  The 8 inputs v = (f0..f4, dx, dy, dz) of neighbour j are multiplied by s_j (their maximum -> [2^14, 2^15)) and split
-    // into fp16 planes; B1 = [xh(8) | xl(8)], A = [wh | wh] and [wl | 0] (planes of [W1f | W1x] / u1): two MFMAs per 32-channel chunk
-    // give the three plane products, and since the neighbour is the N index of the product its column is un-scaled per LANE:
-    // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1).  A neighbour's inputs keep 22 bits relative to ITS OWN largest input -- a 1e7-event
-    // hot pixel no longer sets the scale of the other neighbours, which is what the exact fp32 layer 1 used to guarantee -- no
-    // layer-1 table is computed, stored or gathered (48 B instead of 512 B per neighbour), and one fma replaces three.
+    // NEIGHBOUR.  The inputs of neighbour j -- features f0..f4 and relative xyz -- are two groups with their own weights (W1f / uf,
+    // W1x / ux, planes built here) and their own input factors sigma_f = kappa_j uf, sigma_x = kappa_j ux, where
+    // kappa_j = min(s_f / uf, s_x / ux) and s_g puts the group's largest input at [2^14, 2^15): both groups accumulate kappa_j times
+    // their term in ONE accumulator, the group with the larger (input x weight) bound sits at full scale and the other keeps 22 bits
+    // relative to that bound -- what fp32 itself does.  (One factor for all 8 inputs was not enough: a checkpoint with 1e6 x larger
+    // hidden features and 1e-6 x smaller feature weights left the coordinates 2^-23 below the features and cost 2e-5, fuzz case
+    // profiles/r4_fuzz_modes.txt.)  B1 = [xh(8) | xl(8)], A = [wh | wh] and [wl | 0]: two MFMAs per 32-channel chunk give the three plane
+    // products, and since the neighbour is the N index of the product its column is un-scaled per LANE:
+    // s1 H1 = relu(D1 (s1 / kappa_j) + s1 b1).  A neighbour's inputs are scaled by its OWN maxima -- a 1e7-event hot pixel no longer
+    // sets the scale of the other neighbours, which is what the exact fp32 layer 1 used to guarantee -- no layer-1 table is
+    // computed, stored or gathered (48 B instead of 512 B per neighbour), and one fma replaces three.
     constexpr bool L1F = (NS == 2) && !ROWS;
 #ifdef EV2H_FRAG_PIPE_ALL
     constexpr bool FRAG_PIPE = true;
@@ -185,15 +190,15 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
     } else if constexpr (!ROWS) {
         if (fmode) {
-            // A tiles of layer 1: row i = [wh(v0..v7) | wh(v0..v7)] then [wl(v0..v7) | 0], v = (f0..f4, dx, dy, dz), planes of W / u1
-            const float iu = 1.f / p.u1;                          // (power of two: exact)
+            // A tiles of layer 1: row i = [wh(v0..v7) | wh(v0..v7)] then [wl(v0..v7) | 0], v = (f0..f4, dx, dy, dz), planes of W1f / uf, W1x / ux
+            const float iu = 1.f / p.u1f, iux = 1.f / p.u1x;      // (powers of two: exact)
             for (int i = tid; i < C1; i += WV * 64) {
                 const float4 w = p.W1x[i];
                 float k[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) k[j] = 0.f;
                 for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iu;
-                k[5] = w.x * iu; k[6] = w.y * iu; k[7] = w.z * iu;
+                k[5] = w.x * iux; k[6] = w.y * iux; k[7] = w.z * iux;
                 unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
         float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
         u32x4 b1f = {0u, 0u, 0u, 0u};                      // L1M / L1F: the B operand of the layer-1 MFMA
-        float cj = 1.f;                                    // L1F: u1 s1 / s_j of this lane's neighbour
+        float cj = 1.f;                                    // L1F: s1 / kappa_j of this lane's neighbour
         // ROWS: raw = (w0 T0 + w1 T1) + w2 T2 of chunk c (pointnet2_utils.py:303 applied to the layer-1 table; the table is stored
         // scaled by s1 in F16X2, so the blend is s1 H1 before the ReLU)
         f32x4 trw[ROWS ? 3 : 1][4];
@@ -402,15 +407,19 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 if constexpr (L1F) {
                     // B1 = [xh(v0..v7) | xl(v0..v7)], v = (f0..f4, dx, dy, dz) of this lane's neighbour times its own power of two s_j
                     float v[8] = {f0_cur.x, f0_cur.y, f0_cur.z, f0_cur.w, f1_cur.x, dx, dy, dz};
-                    float m = fmaxf(fabsf(v[0]), fabsf(v[1]));
+                    const float af = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fabsf(v[4]));
+                    const float ax = fmaxf(fmaxf(fabsf(v[5]), fabsf(v[6])), fabsf(v[7]));
+                    const float kap = fminf(f16x2_scale(__float_as_uint(af)) * (1.f / p.u1f), f16x2_scale(__float_as_uint(ax)) * (1.f / p.u1x));
+                    const float sgf = kap * p.u1f, sgx = kap * p.u1x;
+                    cj = s1 * pow2_inverse(kap);
 #pragma unroll
-                    for (int j = 2; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
-                    const float sj = f16x2_scale(__float_as_uint(m));
-                    cj = (p.u1 * s1) * pow2_inverse(sj);
+                    for (int j = 0; j < 5; ++j) v[j] *= sgf;
+#pragma unroll
+                    for (int j = 5; j < 8; ++j) v[j] *= sgx;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         unsigned o[2];
-                        split_planes<2>(v[2 * w] * sj, v[2 * w + 1] * sj, o);
+                        split_planes<2>(v[2 * w], v[2 * w + 1], o);
                         b1f[w] = half ? o[1] : o[0];
                     }
                 }
@@ -1003,7 +1012,8 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
         EV2H_CHECK_ARG((d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_F16X2) && d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 &&
                        d->ldf >= 8 && (d->ldf % 4) == 0 && d->ldw1f >= d->nfeat);
         p.feat = d->feat; p.ldf = d->ldf; p.W1f = d->W1f; p.ldw1f = d->ldw1f; p.b1 = d->b1; p.nfeat = d->nfeat;
-        p.u1 = d->w1_unscale > 0.f ? d->w1_unscale : 1.f;
+        p.u1f = d->w1f_unscale > 0.f ? d->w1f_unscale : 1.f;
+        p.u1x = d->w1x_unscale > 0.f ? d->w1x_unscale : 1.f;
         if (d->precision == EV2H_PREC_F16X2 && d->feat_amax) {
             EV2H_CHECK_ARG(d->dmax > 0.f && d->w1f_norm >= 0.f && d->b1_max >= 0.f && d->w1x_norm >= 0.f && d->w2_norm >= 0.f && d->b2_max >= 0.f);
             p.feat_amax = d->feat_amax; p.w1f_norm = d->w1f_norm; p.b1_max = d->b1_max;

@@ -160,7 +160,8 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
         d.feat, d.ldf, d.W1f, d.ldw1f, d.b1, d.nfeat = feat.data_ptr(), feat.shape[2], W1fc.data_ptr(), W1fc.shape[1], b1c.data_ptr(), W1fc.shape[1]
         if precision == "f16x2":
             from .pack import NS_OF, plane_unscale
-            d.w1_unscale = plane_unscale(torch.cat([W1fc, W1x[:, :3]], 1).detach().cpu().double().numpy(), NS_OF[precision])
+            d.w1f_unscale = plane_unscale(W1fc.detach().cpu().double().numpy(), NS_OF[precision])
+            d.w1x_unscale = plane_unscale(W1x[:, :3].detach().cpu().double().numpy(), NS_OF[precision])
             if feat_amax is not None:            # F16X2 range handling of the feature mode (ev2h_sa_desc.feat_amax)
                 d.feat_amax, d.dmax = feat_amax.data_ptr(), dmax
                 d.w1f_norm, d.b1_max = float(W1fc.abs().sum(1).max()) * (1 + 1e-6), float(b1c.abs().max()) * (1 + 1e-6)

@@ -204,17 +204,17 @@ typedef struct ev2h_sa_desc {
     /* BF16 and F16X2, optional: layer 1 straight from the raw feature rows, on the matrix pipe -- P1 is then not needed (may be NULL)
      * and no layer-1 table has to be computed or gathered: feat [B][Npts][ldf] (first nfeat <= 5 columns used, ldf >= 8: the forward's
      * feat8 / hf8 rows), W1f [C1][ldw1f] and b1 [C1] the folded layer-1 feature weights and bias of this branch.
-     * BF16: inputs enter as two bf16 planes (16 bits), weights as bf16.  F16X2: every neighbour's 8 inputs (features, relative xyz)
-     * are scaled by their OWN power of two before the fp16 split (a neighbour's values keep 22 bits relative to its own largest
-     * input, whatever the rest of the window holds); w1_unscale = the power-of-two plane factor of [W1f | W1x] (ev2h_plane_unscale
-     * of the two matrices side by side); range handling (optional): feat_amax [B] = the range record of the feature rows,
+     * BF16: inputs enter as two bf16 planes (16 bits), weights as bf16.  F16X2: every neighbour's feature values and relative xyz are
+     * scaled by powers of two of their OWN (derived from that neighbour's maxima and from the two weight blocks' plane factors
+     * w1f_unscale / w1x_unscale = ev2h_plane_unscale of W1f and of W1x), so a neighbour's values keep 22 bits relative to its own
+     * largest term whatever the rest of the window holds; range handling (optional): feat_amax [B] = the range record of the feature rows,
      * w1f_norm / b1_max = max row L1 norm of W1f / max |b1| (with w1x_norm, dmax, w2_norm, b2_max above; p1_scale / p1_amax unused). */
     const float* feat; int ldf;
     const float* W1f; int ldw1f;
     const float* b1;
     int nfeat;
     const uint32_t* feat_amax;
-    float w1f_norm, b1_max, w1_unscale;
+    float w1f_norm, b1_max, w1f_unscale, w1x_unscale;
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
@@ -387,7 +387,7 @@ typedef struct ev2h_sa_branch {
     const void* W2s; const void* W3s;   /* 16-bit tile images (NULL unless precision != F32) */
     float w2_unscale, w3_unscale;       /* see ev2h_sa_desc */
     float w1x_norm, w2_norm, b2_max;    /* F16X2 range bounds as in ev2h_sa_desc; filled by ev2h_pack_weights */
-    float w1_unscale;                   /* F16X2: power-of-two plane factor of this branch's [W1f | W1x] (ev2h_sa_desc.w1_unscale) */
+    float w1f_unscale, w1x_unscale;     /* F16X2: power-of-two plane factors of this branch's W1f and W1x (ev2h_sa_desc.w1f_unscale / w1x_unscale) */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */

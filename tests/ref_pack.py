@@ -546,7 +546,8 @@ class PackedWeights:
             br.C1, br.C2, br.C3, br.K, br.radius = C1, C2, C3, K, float(r)
             # F16X2 range bounds (ev2h_sa_desc): rounded up a little so that fp32 rounding can never make a bound too small
             br.w1x_norm = _l1(Ws[0][:, nfeat:]) * (1 + 1e-6)
-            br.w1_unscale = plane_unscale(Ws[0], self.ns)
+            br.w1f_unscale = plane_unscale(Ws[0][:, :nfeat], self.ns)
+            br.w1x_unscale = plane_unscale(Ws[0][:, nfeat:], self.ns)
             br.w2_norm = _l1(Ws[1]) * (1 + 1e-6)
             br.b2_max = float(np.abs(bs[1]).max()) * (1 + 1e-6)
             if self.ns:
