@@ -26,7 +26,7 @@ struct GemmBP {
     const float* post_scale; const float* post_shift;
     int taps; int Kc; int rows_per_seq;
     int rowmax_rows;
-    float w_unscale;        // power of two: the W planes are those of W / w_unscale, products are multiplied back (pack.py: plane_unscale)
+    float w_unscale;        // power of two: the W planes are those of W / w_unscale, products are multiplied back (csrc/pack.hip: plane_unscale)
     // f16x2 activation range (planes.hpp header; all optional, ignored by the other modes)
     const unsigned* x_amax; const unsigned* x_amax2; int x_group_rows;   // max|X| per group of x_group_rows rows (max of the two sources)
     unsigned* y_amax; int y_group_rows;                                   // out: atomicMax of |Y| per group of output rows
@@ -300,7 +300,7 @@ int launch_gb(const GemmBP& p, hipStream_t st) {
 
 // ---------------------------------------------------------------------------------------- wide tile, pre-split W
 // 128 x 256 x 32 tiles for the big layers (N >= 192): W arrives as host-packed bf16 plane images of the LDS
-// tile (ev2hands_amd/pack.py: gemm_bf16_w_image) and is streamed by LDS-DMA; only X is split on the fly.
+// tile (csrc/pack.hip: gemm_image) and is streamed by LDS-DMA; only X is split on the fly.
 // 8 waves as 2 x 4, each wave 64 x 64 = 2 x 2 accumulator tiles: 12 fragment reads feed 24 MFMAs.
 constexpr int GW_BN = 256;
 

@@ -7,9 +7,9 @@
 //                     tools/ubench/mfma_f16_denorm.hip)
 //   NS = 3  "bf16x3"  x = h + m + l, three bf16 planes by exact truncation (8 + 8 + 8 bits); products hl, lh, mm,
 //                     hm, mh, hh (dropped terms O(2^-24)); full fp32 range
-// Smallest terms are accumulated first.  The same splits are applied to the weights on the host (pack.py).
+// Smallest terms are accumulated first.  The same splits are applied to the weights on the host (csrc/pack.hip).
 //
-// Range of f16x2 (fp16 has 5 exponent bits).  Weights: the host takes the planes of W / u, u a power of two (pack.py:
+// Range of f16x2 (fp16 has 5 exponent bits).  Weights: the host takes the planes of W / u, u a power of two (csrc/pack.hip:
 // plane_unscale).  Activations: every tensor a contraction reads carries a per-window absolute maximum ("amax", the bit
 // pattern of a non-negative float, kept up to date with integer atomicMax by the kernel that produces the tensor); the
 // consumer multiplies its rows by the power of two that puts that maximum in [2^14, 2^15) before the split and multiplies the

@@ -140,6 +140,7 @@ struct BallArgs {
     int K[3];
     int32_t* gidx[3];
     int32_t* cnt;   // [B][S][nrad] (may be null)
+    int cpw;        // centroids per workgroup (multiple of 4: one per wave and round)
 };
 
 constexpr int BALL_CTR_PER_WG = 32, BALL_UNR = 4;
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
         __syncthreads();
     }
 
-    const int s_begin = blockIdx.x * BALL_CTR_PER_WG;
-    for (int s = s_begin + wave; s < s_begin + BALL_CTR_PER_WG && s < S; s += 4) {
+    const int s_begin = blockIdx.x * a.cpw;
+    for (int s = s_begin + wave; s < s_begin + a.cpw && s < S; s += 4) {
         const float4 c = ctr4[(size_t)b * S + s];
         int cnt[3] = {0, 0, 0};
         int first[3] = {0, 0, 0};
@@ -266,26 +267,37 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
     // each wave interpolates 64 of the block's points, lanes across channels (float4)
     const int D4 = D >> 2;
     float am = 0.f;                       // max |value| written by this lane (range record)
+    // four points per iteration: their twelve row loads are in flight together (one point at a time left a wave waiting for a
+    // dependent global load per point: 44 us for fp2's 2-workgroup launch at one window, tools/debug/latency_timeline.py)
 #pragma unroll 1
-    for (int t = wave * 64; t < wave * 64 + 64; ++t) {
-        const int nn = blockIdx.x * NN_PTS_PER_WG + t;
-        if (nn >= N1) break;
-        const int j0 = sidx[t * 3 + 0], j1 = sidx[t * 3 + 1], j2 = sidx[t * 3 + 2];
-        const float w0 = sw[t * 3 + 0], w1 = sw[t * 3 + 1], w2 = sw[t * 3 + 2];
-        const float4* f0 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j0) * ldf2);
-        const float4* f1 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j1) * ldf2);
-        const float4* f2 = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + j2) * ldf2);
-        float4* o = reinterpret_cast<float4*>(out + ((size_t)b * N1 + nn) * ldo);
+    for (int t0 = wave * 64; t0 < wave * 64 + 64; t0 += 4) {
+        if (blockIdx.x * NN_PTS_PER_WG + t0 >= N1) break;
         for (int c = lane; c < D4; c += 64) {
-            const float4 a = f0[c], bq = f1[c], cq = f2[c];
-            float4 r;
-            // torch.sum(dim=2) of the three weighted rows: (a*w0 + b*w1) + c*w2, products rounded first
-            r.x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w0), __fmul_rn(bq.x, w1)), __fmul_rn(cq.x, w2));
-            r.y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w0), __fmul_rn(bq.y, w1)), __fmul_rn(cq.y, w2));
-            r.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(bq.z, w1)), __fmul_rn(cq.z, w2));
-            r.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(bq.w, w1)), __fmul_rn(cq.w, w2));
-            o[c] = r;
-            am = fmaxf(fmaxf(am, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            float4 a[4], bq[4], cq[4];
+            float w0[4], w1[4], w2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u;
+                const int j0 = sidx[t * 3 + 0], j1 = sidx[t * 3 + 1], j2 = sidx[t * 3 + 2];
+                w0[u] = sw[t * 3 + 0]; w1[u] = sw[t * 3 + 1]; w2[u] = sw[t * 3 + 2];
+                const bool live = blockIdx.x * NN_PTS_PER_WG + t < N1;          // (sidx / sw of a dead slot were never written)
+                a[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j0 : 0)) * ldf2)[c];
+                bq[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j1 : 0)) * ldf2)[c];
+                cq[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j2 : 0)) * ldf2)[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int nn = blockIdx.x * NN_PTS_PER_WG + t0 + u;
+                if (nn >= N1) break;
+                float4 r;
+                // torch.sum(dim=2) of the three weighted rows: (a*w0 + b*w1) + c*w2, products rounded first
+                r.x = __fadd_rn(__fadd_rn(__fmul_rn(a[u].x, w0[u]), __fmul_rn(bq[u].x, w1[u])), __fmul_rn(cq[u].x, w2[u]));
+                r.y = __fadd_rn(__fadd_rn(__fmul_rn(a[u].y, w0[u]), __fmul_rn(bq[u].y, w1[u])), __fmul_rn(cq[u].y, w2[u]));
+                r.z = __fadd_rn(__fadd_rn(__fmul_rn(a[u].z, w0[u]), __fmul_rn(bq[u].z, w1[u])), __fmul_rn(cq[u].z, w2[u]));
+                r.w = __fadd_rn(__fadd_rn(__fmul_rn(a[u].w, w0[u]), __fmul_rn(bq[u].w, w1[u])), __fmul_rn(cq[u].w, w2[u]));
+                reinterpret_cast<float4*>(out + ((size_t)b * N1 + nn) * ldo)[c] = r;
+                am = fmaxf(fmaxf(am, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+            }
         }
     }
     if (amax) {                          // range record of the interpolated rows (f16x2)
@@ -363,7 +375,11 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
         a.gidx[i] = gidx[i];
     }
     a.cnt = cnt;
-    dim3 grid(ceil_div(S, BALL_CTR_PER_WG), B);
+    // 32 centroids per workgroup amortise the staging of the window's points; a launch that would leave CUs idle (a few windows at a
+    // time: 16 workgroups for enc.sa1 at B = 1) takes fewer per workgroup instead -- same per-centroid arithmetic, same results
+    a.cpw = BALL_CTR_PER_WG;
+    while (a.cpw > 4 && (long)ceil_div(S, a.cpw) * B < 256) a.cpw >>= 1;
+    dim3 grid(ceil_div(S, a.cpw), B);
     // Windows above EV2H_BALL_LDS_MAX points (default 2048: the reference's operating point keeps the LDS form, measured neutral there) read their points from L2 instead of staging them in LDS: at N = 8192 the
     // 128 KB of staged points leave ONE 4-wave workgroup per CU, and the scan is latency-bound -- the L2 form is 3x faster there
     // (1.74 -> ~0.5 ms per 128 windows; BASELINE config 5's shape +14.6 % windows/s, same-box A/B).  Same arithmetic, same results.

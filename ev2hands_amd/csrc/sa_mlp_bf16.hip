@@ -98,7 +98,7 @@ struct SaBCfg {
     static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
     static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
     // F16X2 with 1..4 channels left over after the last full 32-channel tile (C2 = 196: channels 192..195): the three plane
-    // products of those channels share MFMAs instead of taking three each (pack.py builds the matching images):
+    // products of those channels share MFMAs instead of taking three each (csrc/pack.hip builds the matching images):
     //  * layer 2, last tile: rows 8..11 of the tile's HIGH-plane image hold the LOW plane of rows 0..3, so (A = high image,
     //    B = xh) yields wh*xh in D rows 0..3 and wl*xh in rows 8..11 -- the separate (wl, xh) MFMA is dropped and rows 8..11 are
     //    added to rows 0..3 in registers (same lane: D rows 8..11 are registers 4..7 of the lower half-wave);
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
         if constexpr (Cfg::PACK4) {
             // last k-block: slots [xh(4) | xl(4)] in the lower half-wave, [xh(4) | 0] in the upper one (which gets the values from
-            // its partner lane: same neighbour, other half); pack.py stores [wh | wh | wl | 0] at these positions of the W3 image
+            // its partner lane: same neighbour, other half); the packer stores [wh | wh | wl | 0] at these positions of the W3 image
             const unsigned h01 = h2p[0][T2 - 1][0][0], h23 = h2p[0][T2 - 1][0][1];
             const unsigned l01 = h2p[1][T2 - 1][0][0], l23 = h2p[1][T2 - 1][0][1];
             const unsigned ph01 = (unsigned)__shfl_xor((int)h01, 32, 64), ph23 = (unsigned)__shfl_xor((int)h23, 32, 64);
@@ -934,8 +934,8 @@ static int dispatch_fp(const SaBP& p, const ev2h_fp_desc* d, hipStream_t st) {
     return EV2H_ERR_ARG;
 }
 
-// The tile-image geometry the host packer must reproduce (ev2hands_amd/pack.py: sa_bf16_images, gemm_bf16_w_image): ONE source of
-// truth -- pack.py asserts its own numbers against this at load time.
+// The tile-image geometry the host packer must reproduce (csrc/pack.hip: sa_images, gemm_image; tests/ref_pack.py): ONE source of
+// truth -- both assert their own numbers against this on every pack.
 int ev2h_gemm_tile_geometry(int ns, int out[2]);
 namespace {
 template <int C1, int C2, int C3, int NS>

@@ -100,7 +100,7 @@ class TEHNet(nn.Module):
         # only if every output agrees with "bf16x3" to AUTO_TOLERANCE and the segmentation argmax is identical; else "bf16x3"
         self.precision = os.getenv("EV2H_PRECISION", "f16x2")
         self._auto = None             # (pack key of the weights, chosen mode, report) of the last "auto" decision
-        # exact power-of-two equalisation of the hidden channels when the checkpoint is packed (pack.py: equalize_channels): the
+        # exact power-of-two equalisation of the hidden channels when the checkpoint is packed (ev2h_pack_weights, csrc/pack.hip: equalize_channels): the
         # fp32 function is unchanged bit for bit, the 16-bit planes see well-conditioned operands whatever the BatchNorm scales are
         self.equalize = True
         self.left_query_conv = _query_conv()
