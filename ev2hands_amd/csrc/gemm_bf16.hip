@@ -689,6 +689,114 @@ int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
     return EV2H_OK;
 }
 
+// ---------------------------------------------------------------------------------------- small-grid variant
+// 64 x 64 x 32 tiles, 4 waves (2 x 2, each ONE 32 x 32 accumulator), two LDS buffers, for launches whose 128 x 128 tiling gives fewer
+// than 65 workgroups (one to a few windows at a time: the M = 128 B layers).  There a K step of the big tile -- the split of 128 rows
+// plus 24 MFMAs per wave, ~1.2 us with nobody else on the CU -- is the latency of the whole layer (17 steps for K = 520: 30 us, eleven
+// such layers on the critical path of a one-window forward); a quarter-size tile puts four times the workgroups on the idle chip.
+// Every output element accumulates the same products in the same order as in the big-tile kernels (k tiles ascending, the two
+// 16-column k blocks, the plane products): bit-identical, so the choice (by launch size) never shows in a result.
+template <int NS>
+struct GSCfg {
+    static constexpr int RS = NS * 64 + 16;
+    static constexpr int A_BYTES = 64 * RS, B_BYTES = 64 * RS, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;
+};
+
+template <int NS>
+__global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_small_kernel(GemmBP p, const char* __restrict__ Ws) {
+    using Cfg = GSCfg<NS>;
+    constexpr int RS = Cfg::RS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int L = xcd_remap(blockIdx.x, p.nblk);
+    const int tn = L % p.tiles_n, tm = L / p.tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int lrow = tid >> 2, lseg = tid & 3;            // loader: row, 8-wide k quarter
+    const int nk = (p.K + GB_BK - 1) / GB_BK;
+    const float xs = x_row_scale<NS>(p, m0);
+    f32x4 r0, r1;
+    bool ok = true;
+    auto gload = [&](int kt) {
+        const int k = kt * GB_BK + lseg * 8, m = m0 + lrow;
+        ok = (m < p.M) && (k < p.K);                       // K % 8 == 0: a segment lies inside the row or behind it
+        const float* g = p.X + (ok ? (long)m : 0) * p.ldx + (ok ? k : 0);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(r0), "=&v"(r1) : "v"(g) : "memory");
+    };
+    auto commit = [&](char* A) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1) : : "memory");
+        f32x4 a = r0, b = r1;
+        if (!ok) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+        scale_rows<NS>(a, xs); scale_rows<NS>(b, xs);
+        unsigned q[4][NS];
+        split_planes<NS>(a[0], a[1], q[0]);
+        split_planes<NS>(a[2], a[3], q[1]);
+        split_planes<NS>(b[0], b[1], q[2]);
+        split_planes<NS>(b[2], b[3], q[3]);
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            u32x4 v = {q[0][s_], q[1][s_], q[2][s_], q[3][s_]};
+            *reinterpret_cast<u32x4*>(A + lrow * RS + s_ * 64 + lseg * 16) = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0) lgkmcnt(0)
+    };
+    auto dma_b = [&](int kt, char* B) {                    // this tile's 64 rows of the 128-row image tile
+        const char* src = Ws + ((size_t)(tn >> 1) * nk + kt) * (size_t)(GO_BN * RS) + (size_t)(tn & 1) * Cfg::B_BYTES;
+        for (int off = wave * 1024; off < Cfg::B_BYTES; off += 4 * 1024)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(B + off), 16, 0, 0);
+    };
+    static_assert(Cfg::B_BYTES % 1024 == 0, "half an image tile must be a whole number of 1 KiB DMA pieces");
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    auto mma = [&](const char* A, const char* B) {
+        const char* pa = A + (wm * 32 + l31) * RS + half * 16;
+        const char* pb = B + (wn * 32 + l31) * RS + half * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            u32x4 a[NS], b[NS];
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                a[s_] = *reinterpret_cast<const u32x4*>(pa + s_ * 64 + m * 32);
+                b[s_] = *reinterpret_cast<const u32x4*>(pb + s_ * 64 + m * 32);
+            }
+#pragma unroll
+            for (int q = 0; q < Planes<NS>::NPROD; ++q) acc[0][0] = mfma_planes<NS>(a[Planes<NS>::A[q]], b[Planes<NS>::B[q]], acc[0][0]);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);              // all fragment reads returned before a tile is overwritten
+    };
+    dma_b(0, smem + Cfg::A_BYTES);
+    gload(0);
+    commit(smem);
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();                    // buffer kt & 1 is complete; nobody reads the other one any more
+        const bool more = kt + 1 < nk;
+        char* cur = smem + (kt & 1) * Cfg::BUF;
+        char* nxt = smem + ((kt + 1) & 1) * Cfg::BUF;
+        if (more) { dma_b(kt + 1, nxt + Cfg::A_BYTES); gload(kt + 1); }
+        mma(cur, cur + Cfg::A_BYTES);
+        if (more) commit(nxt);
+    }
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue<NS, 1, 1, false>(p, acc, m0, wm * 32, n0 + wn * 32, wm, wn * 32, 64, reinterpret_cast<float*>(smem), tid);
+}
+
+template <int NS>
+int launch_go_small(GemmBP p, const char* Ws, hipStream_t st) {
+    p.tiles_n = ceil_div(p.N, 64);
+    p.nblk = ceil_div(p.M, 64) * p.tiles_n;
+    static PerDevice attr_set{};
+    EV2H_ONCE_PER_DEVICE(attr_set,
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_small_kernel<NS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GSCfg<NS>::LDS_BYTES)););
+    gemm_nt_bf16_small_kernel<NS><<<p.nblk, GO_THREADS, GSCfg<NS>::LDS_BYTES, st>>>(p, Ws);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
 template <int NS>
 constexpr int go_pipe_lds() { return 2 * GOCfg<NS, false>::LDS_BYTES; }
 
@@ -708,7 +816,9 @@ int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
     static const bool no_tap3 = getenv("EV2H_GEMM_NO_TAP3") != nullptr;       // A/B switch
     if (p.taps == 3 && !no_tap3 && p.Kc % GB_BK == 0 && p.rows_per_seq % GB_BM == 0 && p.M % p.rows_per_seq == 0)
         return launch_go_t<NS, true>(p, Ws, st);
-    static const bool no_pipe = getenv("EV2H_GEMM_NO_PIPE") != nullptr;       // A/B switch
+    static const bool no_pipe = getenv("EV2H_GEMM_NO_PIPE") != nullptr;       // A/B switches
+    static const bool no_small = getenv("EV2H_GEMM_NO_SMALL") != nullptr;
+    if (p.nblk <= 64 && p.rowmax_rows == 0 && p.taps == 1 && !no_small && !no_pipe) return launch_go_small<NS>(p, Ws, st);   // quarter-size tiles
     if (p.nblk <= 128 && !no_pipe) return launch_go_pipe<NS>(p, Ws, st);      // fewer workgroups than CUs: hide the K-step chain inside the workgroup
     return launch_go_t<NS, false>(p, Ws, st);
 }

@@ -7,6 +7,7 @@
 // the third-party manopth ManoLayer.forward (use_pca=True, ncomps=6, flat_hand_mean=False,
 // axis-angle root) -- not vendored in the reference; algorithm restated in oracle/mano_oracle.py.
 // Rotation formula: /root/reference/src/Ev2Hands/losses.py:14-51.
+#include <cstdlib>
 #include "common.hpp"
 #include "ev2hands_hip.h"
 
@@ -19,6 +20,7 @@ struct ManoP {
     const float* params; int ldp;
     float* verts; float* joints;
     size_t verts_stride, joints_stride;       // floats between consecutive windows
+    int parts;                                // workgroups per window
 };
 
 // level-ordered chain: parents of joint k (MANO kintree), -1 for the root
@@ -83,7 +85,11 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     __shared__ float s_G[NJ][12];      // rows of [R | t]
     __shared__ float s_A[NJ][12];
     __shared__ float s_tip[5][3];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // p.parts workgroups per (window, hand) at small batches: each repeats the (tiny) joint chain and skins a quarter of the vertices.
+    // One workgroup pulls the 1.35 MB blend-shape matrix through ONE CU (46 us for a one-window forward, at its very end); a vertex's
+    // arithmetic does not depend on who computes it.
+    const int b = blockIdx.x / p.parts, part = blockIdx.x % p.parts, tid = threadIdx.x;
+    const int vper = (NV + p.parts - 1) / p.parts, v_begin = part * vper, v_end = min(NV, v_begin + vper);
     const float* prm = p.params + (size_t)b * p.ldp;
     const int nc = p.c.ncomps;
     const float* betas = prm + 3 + nc;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
 
     // 7. blend shapes + skinning per vertex
     const float trx = transl[0], try_ = transl[1], trz = transl[2];
-    for (int v = tid; v < NV; v += MANO_THREADS) {
+    for (int v = v_begin + tid; v < v_end; v += MANO_THREADS) {
         float vp[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -184,6 +190,9 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     // 8. 16 chain joints + 5 fingertip vertices, reordered
     if (tid < 21) {
         const int src = c_joint_reorder[tid];
+        // (chain joints: the first part; a fingertip: the part that skinned its vertex)
+        const bool mine = (src < NJ) ? part == 0 : (p.c.tips[src - NJ] >= v_begin && p.c.tips[src - NJ] < v_end);
+        if (!mine) return;
         float j[3];
         for (int c = 0; c < 3; ++c) j[c] = (src < NJ) ? s_G[src][4 * c + 3] : s_tip[src - NJ][c];
         float* oj = p.joints + (size_t)b * p.joints_stride + tid * 3;
@@ -204,7 +213,9 @@ extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp
     EV2H_CHECK_ARG((verts_stride == 0 || verts_stride >= (size_t)NV * 3) && (joints_stride == 0 || joints_stride >= 63));
     p.c = *c; p.params = params; p.ldp = ldp; p.verts = verts; p.joints = joints;
     p.verts_stride = verts_stride ? verts_stride : (size_t)NV * 3; p.joints_stride = joints_stride ? joints_stride : 63;
-    mano_kernel<<<B, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
+    static const int forced_parts = getenv("EV2H_MANO_PARTS") ? atoi(getenv("EV2H_MANO_PARTS")) : 0;      // A/B switch
+    p.parts = forced_parts > 0 ? forced_parts : (B <= 32 ? 4 : 1);
+    mano_kernel<<<B * p.parts, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -573,7 +573,7 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
 AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_EXTRA_OVERLAP", "0", True), ("EV2H_COORD_OVERLAP", "0", True), ("EV2H_SA_NO_SKIP", "1", True), ("EV2H_SA_STREAMED", "1", True),
                ("EV2H_NO_TABLE_KERNEL", "1", False), ("EV2H_GEMM_NO_TAP3", "1", True), ("EV2H_NO_SKINNY_KERNEL", "1", False),
                ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFOLDED", "1", False),
-               ("EV2H_SA_NO_SPREAD", "1", True), ("EV2H_GEMM_NO_PIPE", "1", True), ("EV2H_L1_TABLE", "1", False)]
+               ("EV2H_SA_NO_SPREAD", "1", True), ("EV2H_GEMM_NO_PIPE", "1", True), ("EV2H_GEMM_NO_SMALL", "1", True), ("EV2H_L1_TABLE", "1", False)]
 
 _AB_SCRIPT = """
 import os, sys, torch
