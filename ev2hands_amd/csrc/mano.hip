@@ -85,6 +85,7 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     __shared__ float s_G[NJ][12];      // rows of [R | t]
     __shared__ float s_A[NJ][12];
     __shared__ float s_tip[5][3];
+    __shared__ float s_vp[NV * 3];     // posed-shape vertices of this workgroup's part
     // p.parts workgroups per (window, hand) at small batches: each repeats the (tiny) joint chain and skins a quarter of the vertices.
     // One workgroup pulls the 1.35 MB blend-shape matrix through ONE CU (46 us for a one-window forward, at its very end); a vertex's
     // arithmetic does not depend on who computes it.
@@ -148,22 +149,26 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     }
     __syncthreads();
 
-    // 7. blend shapes + skinning per vertex
+    // 7a. blend shapes: one thread per (vertex, coordinate) -- the 145-term sums of a vertex's three coordinates are independent, so
+    //     they run side by side (the same sums in the same order as one thread per vertex computed them: bit-identical) and the
+    //     column reads of consecutive threads are consecutive addresses
+    for (int task = tid; task < (v_end - v_begin) * 3; task += MANO_THREADS) {
+        const int vc = v_begin * 3 + task;                 // = v * 3 + c
+        const float* col = p.c.blend_T + vc;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) s = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], s);
+        const float vs = __fadd_rn(s, p.c.v_template[vc]);
+        float q = 0.f;
+#pragma unroll 15
+        for (int k = NB; k < NCOEF; ++k) q = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], q);
+        s_vp[task] = __fadd_rn(vs, q);
+    }
+    __syncthreads();
+    // 7b. skinning per vertex
     const float trx = transl[0], try_ = transl[1], trz = transl[2];
     for (int v = v_begin + tid; v < v_end; v += MANO_THREADS) {
-        float vp[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* col = p.c.blend_T + v * 3 + c;
-            float s = 0.f;
-#pragma unroll
-            for (int k = 0; k < NB; ++k) s = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], s);
-            const float vs = __fadd_rn(s, p.c.v_template[v * 3 + c]);
-            float q = 0.f;
-#pragma unroll 15
-            for (int k = NB; k < NCOEF; ++k) q = __fmaf_rn(s_coef[k], col[(size_t)k * LDB], q);
-            vp[c] = __fadd_rn(vs, q);
-        }
+        const float vp[3] = {s_vp[(v - v_begin) * 3], s_vp[(v - v_begin) * 3 + 1], s_vp[(v - v_begin) * 3 + 2]};
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
