@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
                                                               int N1, int N2, const float* __restrict__ feat2, int ldf2, int D,
                                                               float* __restrict__ out, int ldo,
                                                               int32_t* __restrict__ nn_idx, float* __restrict__ nn_w,
-                                                              unsigned* __restrict__ amax) {
+                                                              unsigned* __restrict__ amax, int ppw) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* s2 = reinterpret_cast<float4*>(smem_raw);                 // [N2]
     int* sidx = reinterpret_cast<int*>(s2 + N2);                       // [256][3]
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
     for (int p = tid; p < N2; p += 256) s2[p] = pts2[(size_t)b * N2 + p];
     __syncthreads();
 
-    const int n = blockIdx.x * NN_PTS_PER_WG + tid;
-    if (n < N1) {
+    // ppw = query points per workgroup (256, or 64 when the launch would otherwise leave most CUs idle: a few windows at a time)
+    const int n = blockIdx.x * ppw + tid;
+    if (tid < ppw && n < N1) {
         const float4 q = pts1[(size_t)b * N1 + n];
         float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
         int i0 = 0, i1 = 0, i2 = 0;
@@ -269,9 +270,10 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
     float am = 0.f;                       // max |value| written by this lane (range record)
     // four points per iteration: their twelve row loads are in flight together (one point at a time left a wave waiting for a
     // dependent global load per point: 44 us for fp2's 2-workgroup launch at one window, tools/debug/latency_timeline.py)
+    const int pw = ppw >> 2;             // points per wave
 #pragma unroll 1
-    for (int t0 = wave * 64; t0 < wave * 64 + 64; t0 += 4) {
-        if (blockIdx.x * NN_PTS_PER_WG + t0 >= N1) break;
+    for (int t0 = wave * pw; t0 < wave * pw + pw; t0 += 4) {
+        if (blockIdx.x * ppw + t0 >= N1) break;
         for (int c = lane; c < D4; c += 64) {
             float4 a[4], bq[4], cq[4];
             float w0[4], w1[4], w2[4];
@@ -280,14 +282,14 @@ __global__ __launch_bounds__(256) void three_nn_interp_kernel(const float4* __re
                 const int t = t0 + u;
                 const int j0 = sidx[t * 3 + 0], j1 = sidx[t * 3 + 1], j2 = sidx[t * 3 + 2];
                 w0[u] = sw[t * 3 + 0]; w1[u] = sw[t * 3 + 1]; w2[u] = sw[t * 3 + 2];
-                const bool live = blockIdx.x * NN_PTS_PER_WG + t < N1;          // (sidx / sw of a dead slot were never written)
+                const bool live = blockIdx.x * ppw + t < N1;          // (sidx / sw of a dead slot were never written)
                 a[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j0 : 0)) * ldf2)[c];
                 bq[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j1 : 0)) * ldf2)[c];
                 cq[u] = reinterpret_cast<const float4*>(feat2 + ((size_t)b * N2 + (live ? j2 : 0)) * ldf2)[c];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int nn = blockIdx.x * NN_PTS_PER_WG + t0 + u;
+                const int nn = blockIdx.x * ppw + t0 + u;
                 if (nn >= N1) break;
                 float4 r;
                 // torch.sum(dim=2) of the three weighted rows: (a*w0 + b*w1) + c*w2, products rounded first
@@ -407,10 +409,11 @@ extern "C" int ev2h_three_nn_interp(const float* pts1_4, const float* pts2_4, in
     EV2H_CHECK_ARG(pts1_4 && pts2_4);
     EV2H_CHECK_ARG(B > 0 && N1 > 0 && N2 >= 3 && N2 <= 4096);
     if (out) EV2H_CHECK_ARG(feat2 && D > 0 && (D % 4) == 0 && (ldf2 % 4) == 0 && (ldo % 4) == 0);
-    dim3 grid(ceil_div(N1, NN_PTS_PER_WG), B);
+    const int ppw = ((long)ceil_div(N1, NN_PTS_PER_WG) * B < 128) ? 64 : NN_PTS_PER_WG;
+    dim3 grid(ceil_div(N1, ppw), B);
     const size_t lds = (size_t)N2 * sizeof(float4) + NN_PTS_PER_WG * 3 * (sizeof(int) + sizeof(float));
     three_nn_interp_kernel<<<grid, 256, lds, (hipStream_t)stream>>>((const float4*)pts1_4, (const float4*)pts2_4, N1, N2, feat2,
-                                                                    ldf2, D, out, ldo, nn_idx, nn_w, out_amax);
+                                                                    ldf2, D, out, ldo, nn_idx, nn_w, out_amax, ppw);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
