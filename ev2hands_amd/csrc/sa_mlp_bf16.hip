@@ -5,7 +5,13 @@
 //           truncation split x = h + m + l) and the six products hh, hm, mh, mm, hl, lh are accumulated in
 //           fp32 -- dropped terms are O(2^-24), i.e. fp32-class accuracy at 6/16 of the fp32 MFMA cost;
 //   NS = 1  plain bf16 operands (round to nearest even), fp32 accumulate -- BASELINE.json config 3.
-// Layer 1 (gather + exact relative xyz + ReLU), all biases, ReLUs and the max stay in fp32.
+// All biases, ReLUs and the max stay in fp32.  Layer 1 has three forms (see L1M / L1F / the VALU path in the kernel):
+//   * gathered layer-1 table row + exact fp32 relative-xyz fma chain (every mode when the features are a real table: enc.sa2;
+//     BF16X3 always);
+//   * BF16: one MFMA per 32-channel chunk (inputs as two bf16 planes), on top of the table row or -- raw feature rows -- instead of it;
+//   * F16X2 with raw feature rows: two MFMAs per chunk with per-neighbour power-of-two factors for the feature and xyz groups.
+// Other round-4 additions: fragment reads issued a group ahead (FRAG_PIPE), the next strip's gather requested during the current
+// strip (XPF), a group's strips spread over the waves of a workgroup when the grid is smaller than the chip (SaBP::spg).
 //
 // Weight tiles are packed by the host as byte images of the LDS tiles (rows padded by 16 B so that the
 // ds_read_b128 fragment reads are conflict free) and streamed global -> LDS with the LDS-DMA
