@@ -229,6 +229,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
     auto dma_tile = [&](const char* src, char* dst, int bytes) {
         for (int off = wave * 1024; off < bytes; off += WV * 1024) {
+#ifdef EV2H_SAB_DMA_EXPERIMENT      // timing experiment only (WRONG results): move 1 / EV2H_SAB_DMA_EXPERIMENT of the weight bytes
+            if ((off / (WV * 1024)) % EV2H_SAB_DMA_EXPERIMENT) continue;
+#endif
             if (off + lane * 16 < bytes)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);

@@ -119,6 +119,7 @@ def main():
             truth = {"class_logits": o["class_logits"], **{f"{s_}.{k}": o[s_][k] for s_ in ("left", "right") for k in KEYS}}
             print("   f32 mode vs fp32 CPU oracle:", {k: f"{rel(ref[k], truth[k]):.1e}" for k in ref})
         modes = ["f16x2"] + (["bf16x3"] if case % 3 == 0 else [])
+        case_worst = 0.0
         for prec in modes:
             got, gsel = run(net, xyz, inits, prec)
             again, _ = run(net, xyz, inits, prec)
@@ -130,6 +131,7 @@ def main():
                 print(f"   {prec} vs fp32 CPU oracle:", {k: f"{rel(got[k], truth[k]):.1e}" for k in ref})
                 print(f"   {prec} vs f32 mode      :", {k: f"{v:.1e}" for k, v in errs.items()})
             worst = max(worst, max(errs.values()))
+            case_worst = max(case_worst, max(errs.values()))
             if max(errs.values()) > 2e-5:
                 k = max(errs, key=errs.get)
                 msgs.append(f"{prec}: {k} rel err {errs[k]:.2e}")
@@ -143,7 +145,7 @@ def main():
                 msgs.append(f"{prec}: not deterministic")
             if any(not torch.isfinite(v).all() for v in got.values()):
                 msgs.append(f"{prec}: non-finite output")
-        print(f"case {case:3d}: C={C} {kind} B={B} N={N:5d} mhlnes={mh} ckpt={variant:22s} seed={seed:6d}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
+        print(f"case {case:3d}: C={C} {kind} B={B} N={N:5d} mhlnes={mh} ckpt={variant:22s} seed={seed:6d}  {case_worst:.1e}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
         bad += bool(msgs)
         del net
     print(f"{ncases} cases, {bad} with violations, worst relative difference to the exact-fp32 mode {worst:.2e}")
