@@ -19,6 +19,7 @@
 // streamed variant; the narrow MLPs keep all tiles resident in a persistent workgroup (see the kernel's comment).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "planes.hpp"
 #include "ev2hands_hip.h"
 
@@ -153,6 +154,20 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // sets the scale of the other neighbours, which is what the exact fp32 layer 1 used to guarantee -- no layer-1 table is
     // computed, stored or gathered (48 B instead of 512 B per neighbour), and one fma replaces three.
     constexpr bool L1F = (NS == 2) && !ROWS;
+    // L2PIPE / H2FUSE (round 4, late): conversion work of one wave placed between its MFMA groups (see the layer-2 loop and the first
+    // layer-3 step).  Same-box step A/B (profiles/r4_ab_h2fuse_l2pipe.txt): BF16 +1.3 % with H2FUSE, +1.9 % with both; F16X2 +1.1 % with
+    // H2FUSE, and L2PIPE costs it 0.5 % (its widest instantiation then spills 24 bytes) -- so F16X2 keeps the un-pipelined layer 2.
+    // EV2H_BUILD_DEFS=-DEV2H_NO_L2PIPE / -DEV2H_NO_H2FUSE: build without.
+#ifdef EV2H_NO_L2PIPE
+    constexpr bool L2PIPE = false;
+#else
+    constexpr bool L2PIPE = !ROWS && NS == 1 && (C1 / 32) % 2 == 0;
+#endif
+#ifdef EV2H_NO_H2FUSE
+    constexpr bool H2FUSE = false;
+#else
+    constexpr bool H2FUSE = NS <= 2;          // (BF16X3: the widest instantiation would spill)
+#endif
 #ifdef EV2H_FRAG_PIPE_ALL
     constexpr bool FRAG_PIPE = true;
 #else
@@ -271,11 +286,6 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int32_t* gi = nullptr;
     if constexpr (!ROWS) { ctr = p.ctr4[gg]; gi = p.gidx + (size_t)gg * p.K + sw * 32; }
     const int row0 = ROWS ? (gg - b * p.S) * 32 : 0;          // ROWS: first point of this strip inside its window
-    float b3r[ROWS ? T3 : 1];
-    if constexpr (ROWS) {
-#pragma unroll
-        for (int u = 0; u < T3; ++u) b3r[u] = p.b3[32 * u + l31];
-    }
     unsigned am = 0u;
     // f16x2 range: with P1' = s1 P1 (table stored scaled) and d' = s1 d the layer-1 output is H1' = s1 H1 <= a1 + s1 |W1x|_1 dmax
     // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
@@ -512,24 +522,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         if (dbgw && strip == dbg_strip) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         STAMP(1);
-#pragma unroll 1
-        for (int c = 0; c < NC1; ++c) {
-            STAMP(2 + 4 * c);
-            char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0) + (c % CPT) * Cfg::TB2;
-            char* nxt = buf ? wt0 : wt1;
-            if constexpr (!RES) {
-                if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
-            }
-            if (!ROWS && !L1M && !fmode && !Cfg::PREFETCH_P1 && c > 0) {
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + c * 8 + qi(j4));
-            }
-            // layer-1 finish in fp32, then split: lane's channels 32c + 16*half + [0,16) = k-slots of 2 MFMAs
-            u32x4 bp[2][NS];
+        // layer-1 finish in fp32, then split, of SLICE j4 of chunk c: the lane's channels 32c + 8 j4 + 4 half + [0, 4) = two of its 16
+        // k-slots of the chunk (a chunk's 16 slots feed 2 MFMAs per tile: bp[k-block][plane])
+        auto finish_slice = [&](int c, int j4, u32x4 (&bp)[2][NS]) {
             if constexpr (L1M) {
                 // ReLU on the packed bf16 pairs: one v_pk_max_i16 per pair (negative floats are negative int16 patterns)
 #pragma unroll
-                for (int w = 0; w < 8; ++w) {
+                for (int w = 2 * j4; w < 2 * j4 + 2; ++w) {
                     unsigned o[1];
                     split_planes<1>(d1[2 * w], d1[2 * w + 1], o);
                     bp[w >> 2][0][w & 3] = relu_pk_bf16(o[0]);
@@ -537,22 +536,18 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             } else if (fmode) {
                 if constexpr (L1F) {
                     // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1): D register 4q + e of a lane is channel 32c + 8q + 4 half + e
+                    const int q = j4;
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
+                    unsigned lo[2], hi[2];
+                    split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q], cj, bv[0])), relu_sat_f16(__fmaf_rn(d1[4 * q + 1], cj, bv[1])), lo);
+                    split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q + 2], cj, bv[2])), relu_sat_f16(__fmaf_rn(d1[4 * q + 3], cj, bv[3])), hi);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
-                        unsigned lo[2], hi[2];
-                        split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q], cj, bv[0])), relu_sat_f16(__fmaf_rn(d1[4 * q + 1], cj, bv[1])), lo);
-                        split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q + 2], cj, bv[2])), relu_sat_f16(__fmaf_rn(d1[4 * q + 3], cj, bv[3])), hi);
-#pragma unroll
-                        for (int s_ = 0; s_ < 2; ++s_) {
-                            bp[q >> 1][s_][(q & 1) * 2 + 0] = lo[s_];
-                            bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
-                        }
+                    for (int s_ = 0; s_ < 2; ++s_) {
+                        bp[q >> 1][s_][(q & 1) * 2 + 0] = lo[s_];
+                        bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
                     }
                 }
             } else {
-#pragma unroll
-            for (int j4 = 0; j4 < 4; ++j4) {
                 const f32x4* wp = sW1xT + (8 * c + 2 * j4 + half) * 3;
                 const f32x4 wx = wp[0], wy = wp[1], wz = wp[2];
                 f32x4 v;
@@ -580,22 +575,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
                 }
             }
-            }
-            if constexpr (ROWS) {
-                if (c + 1 < NC1) fetch(c + 1);      // in flight under this chunk's MFMAs, blended after them
-            } else if (!L1M && !fmode && Cfg::PREFETCH_P1 && c + 1 < NC1) {
-#pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + qi(j4));
-            }
-            STAMP(3 + 4 * c);
+        };
+        // the MFMAs of one chunk: the 2*T2 (k-block m, tile t) groups are taken two at a time and their MFMAs alternate between the
+        // two tiles' accumulators: anything issued between two MFMAs on the SAME accumulator (here the next fragment reads) costs
+        // ~43 cycles, between MFMAs on different accumulators ~6 (MI355X_MICROARCH.md, latency table)
+        // FRAG_PIPE (BF16): the fragment reads of group pr + 1 are issued BEFORE the MFMAs of group pr (two register sets, order
+        // pinned with scheduling barriers).  Left to itself the compiler emitted read, read, s_waitcnt lgkmcnt(0), MFMA, MFMA per
+        // group -- the full LDS latency in front of every MFMA pair, which with ONE product per operand pair is most of a tile
+        // step (phase timeline, profiles/r4_sa_timeline.txt: 1.0-1.7 us per 14-MFMA chunk whose MFMAs take 0.22 us).
+        // between(pr) runs after the MFMAs of pair pr were issued (L2PIPE: slices of the next chunk's layer-1 finish).
+        auto mfma_groups = [&](const char* cur, u32x4 (&bp)[2][NS], auto&& between) {
             const char* pa = cur + l31 * RS2 + (16 * half) * 2;
-            // the 2*T2 (k-block m, tile t) groups are taken two at a time and their MFMAs alternate between the two tiles'
-            // accumulators: anything issued between two MFMAs on the SAME accumulator (here the next fragment reads) costs
-            // ~43 cycles, between MFMAs on different accumulators ~6 (MI355X_MICROARCH.md, latency table)
-            // FRAG_PIPE (BF16): the fragment reads of group pr + 1 are issued BEFORE the MFMAs of group pr (two register sets, order
-            // pinned with scheduling barriers).  Left to itself the compiler emitted read, read, s_waitcnt lgkmcnt(0), MFMA, MFMA per
-            // group -- the full LDS latency in front of every MFMA pair, which with ONE product per operand pair is most of a tile
-            // step (phase timeline, profiles/r4_sa_timeline.txt: 1.0-1.7 us per 14-MFMA chunk whose MFMAs take 0.22 us).
             auto ld2 = [&](int pr, u32x4 (&x0)[NS], u32x4 (&x1)[NS]) {
                 const int m0 = (2 * pr) / T2, t0 = (2 * pr) % T2, m1 = (2 * pr + 1) / T2, t1 = (2 * pr + 1) % T2;
 #pragma unroll
@@ -624,24 +614,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     if (!(Cfg::PACK4 && t1 == T2 - 1 && PL::A[j] == 1)) h2[t1] = mfma_planes<NS>(a1[PL::A[j]], bp[m1][PL::B[j]], h2[t1]);
                 }
                 if constexpr (FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
+                between(pr);
             }
-            if constexpr (ROWS) {
-                if (c + 1 < NC1) blend();
+        };
+        auto l2_dma = [&](int c) {                      // the next tile step's image into the other buffer
+            if constexpr (!RES) {
+                char* nxt = buf ? wt0 : wt1;
+                if (c % CPT == 0) { if (c + CPT < NC1) dma_w2(c / CPT + 1, nxt); else dma_w3(0, nxt); }
             }
-            if constexpr (L1F) {
-                if (fmode && c + 1 < NC1) d1 = layer1(c + 1);
-            }
-            if constexpr (L1M) {
-                // next chunk's layer 1: issued behind this chunk's MFMAs, converted at the top of the next iteration; its table row
-                // (table mode) was loaded one iteration ago, the row after it is requested now
-                if (c + 1 < NC1) {
-                    d1 = layer1(c + 1);
-                    if (!p.feat && c + 2 < NC1) {
-#pragma unroll
-                        for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
-                    }
-                }
-            }
+        };
+        auto l2_sync = [&](int c) {
             STAMP(4 + 4 * c);
             if constexpr (!RES) {
                 if (c % CPT == CPT - 1) {
@@ -651,6 +633,90 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 }
             }
             STAMP(5 + 4 * c);
+        };
+        u32x4 bpA[2][NS];
+        if constexpr (!L2PIPE) {
+#pragma unroll 1
+            for (int c = 0; c < NC1; ++c) {
+                STAMP(2 + 4 * c);
+                char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0) + (c % CPT) * Cfg::TB2;
+                l2_dma(c);
+#pragma unroll
+                for (int j4 = 0; j4 < 4; ++j4) finish_slice(c, j4, bpA);
+                if constexpr (ROWS) {
+                    if (c + 1 < NC1) fetch(c + 1);      // in flight under this chunk's MFMAs, blended after them
+                } else if (!L1M && !fmode && c + 1 < NC1) {
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 1) * 8 + qi(j4));
+                }
+                STAMP(3 + 4 * c);
+                mfma_groups(cur, bpA, [](int) {});
+                if constexpr (ROWS) {
+                    if (c + 1 < NC1) blend();
+                }
+                if constexpr (L1F) {
+                    if (fmode && c + 1 < NC1) d1 = layer1(c + 1);
+                }
+                if constexpr (L1M) {
+                    // next chunk's layer 1: issued behind this chunk's MFMAs, converted at the top of the next iteration; its table row
+                    // (table mode) was loaded one iteration ago, the row after it is requested now
+                    if (c + 1 < NC1) {
+                        d1 = layer1(c + 1);
+                        if (!p.feat && c + 2 < NC1) {
+#pragma unroll
+                            for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
+                        }
+                    }
+                }
+                l2_sync(c);
+            }
+        } else {
+            // L2PIPE: the layer-1 finish + split of chunk c + 1 is cut into its four slices and placed BETWEEN the MFMA pairs of chunk c
+            // (two operand buffers), so that one wave's conversion runs under its SIMD partner's MFMAs instead of both waves
+            // converting behind the same barrier while the matrix pipe idles (phase timeline: 13 % of an f16x2 strip).
+            u32x4 bpB[2][NS];
+            const bool vtab = !L1M && !fmode;            // layer 1 on the VALU from gathered table rows
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                finish_slice(0, j4, bpA);
+                if (vtab) raw[j4] = *reinterpret_cast<const f32x4*>(prow + 8 + qi(j4));
+            }
+            auto l2_step = [&](int c, u32x4 (&bc)[2][NS], u32x4 (&bn)[2][NS]) {
+                STAMP(2 + 4 * c);
+                char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0) + (c % CPT) * Cfg::TB2;
+                l2_dma(c);
+                const bool more = c + 1 < NC1;
+                if (more) {
+                    if constexpr (L1F) { if (fmode) d1 = layer1(c + 1); }
+                    if constexpr (L1M) {
+                        d1 = layer1(c + 1);
+                        if (!p.feat && c + 2 < NC1) {
+#pragma unroll
+                            for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
+                        }
+                    }
+                }
+                STAMP(3 + 4 * c);
+                mfma_groups(cur, bc, [&](int pr) {
+                    if (more) {
+#pragma unroll
+                        for (int j4 = 0; j4 < 4; ++j4) {
+                            if (j4 * T2 / 4 == pr) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                finish_slice(c + 1, j4, bn);
+                                if (vtab && c + 2 < NC1) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                });
+                l2_sync(c);
+            };
+#pragma unroll 1
+            for (int c = 0; c < NC1; c += 2) {
+                l2_step(c, bpA, bpB);
+                l2_step(c + 1, bpB, bpA);
+            }
         }
 
         STAMP(38);
@@ -675,10 +741,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
         // ReLU in fp32 (the bias is already in), then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
         u32x4 h2p[NS][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
+        // one k-block (8 channels per lane) of tile t; PACK4: the last tile's block 0 is re-packed once both planes exist
+        auto split_half = [&](int t, int m) {
 #pragma unroll
-        for (int t = 0; t < T2; ++t) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 4 * m; k < 4 * m + 4; ++k) {
                 unsigned o[NS];
                 if constexpr (NS == 2) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
                 else if constexpr (NS == 1) { split_planes<NS>(h2[t][2 * k], h2[t][2 * k + 1], o); o[0] = relu_pk_bf16(o[0]); }     // (u2 = 1: no factor)
@@ -686,18 +752,25 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
-        }
-        if constexpr (Cfg::PACK4) {
-            // last k-block: slots [xh(4) | xl(4)] in the lower half-wave, [xh(4) | 0] in the upper one (which gets the values from
-            // its partner lane: same neighbour, other half); the packer stores [wh | wh | wl | 0] at these positions of the W3 image
-            const unsigned h01 = h2p[0][T2 - 1][0][0], h23 = h2p[0][T2 - 1][0][1];
-            const unsigned l01 = h2p[1][T2 - 1][0][0], l23 = h2p[1][T2 - 1][0][1];
-            const unsigned ph01 = (unsigned)__shfl_xor((int)h01, 32, 64), ph23 = (unsigned)__shfl_xor((int)h23, 32, 64);
-            h2p[0][T2 - 1][0][0] = half ? ph01 : h01;
-            h2p[0][T2 - 1][0][1] = half ? ph23 : h23;
-            h2p[0][T2 - 1][0][2] = half ? 0u : l01;
-            h2p[0][T2 - 1][0][3] = half ? 0u : l23;
-        }
+            if constexpr (Cfg::PACK4) {
+                if (t == T2 - 1 && m == 0) {
+                    // last k-block: slots [xh(4) | xl(4)] in the lower half-wave, [xh(4) | 0] in the upper one (which gets the values from
+                    // its partner lane: same neighbour, other half); the packer stores [wh | wh | wl | 0] at these positions of the W3 image
+                    const unsigned h01 = h2p[0][T2 - 1][0][0], h23 = h2p[0][T2 - 1][0][1];
+                    const unsigned l01 = h2p[1][T2 - 1][0][0], l23 = h2p[1][T2 - 1][0][1];
+                    const unsigned ph01 = (unsigned)__shfl_xor((int)h01, 32, 64), ph23 = (unsigned)__shfl_xor((int)h23, 32, 64);
+                    h2p[0][T2 - 1][0][0] = half ? ph01 : h01;
+                    h2p[0][T2 - 1][0][1] = half ? ph23 : h23;
+                    h2p[0][T2 - 1][0][2] = half ? 0u : l01;
+                    h2p[0][T2 - 1][0][3] = half ? 0u : l23;
+                }
+            }
+        };
+        // H2FUSE: only tile 0 is split here; tile t + 1 is split between the MFMA groups of tile t in the FIRST layer-3 step, so that
+        // the conversion (VALU) of one wave runs under the MFMAs of its SIMD partner instead of both waves converting while the matrix
+        // pipe idles (phase timeline: "h2 ReLU + split" was 8 % of a strip).  Same values, same order of the contraction.
+#pragma unroll
+        for (int t = 0; t < (H2FUSE ? 1 : T2); ++t) { split_half(t, 0); split_half(t, 1); }
         STAMP(39);
 
         // ---------------- layer 3 + max: D3[neighbour][channel] = H2 (A, registers) x W3 tile (B, LDS, permuted k order)
@@ -715,8 +788,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         // (the row chains keep one tile at a time: their store addresses would not fit the scalar registers twice)
         constexpr int TPS = (!ROWS && (RES || UPT == 2)) ? 2 : 1;
         static_assert(T3 % TPS == 0, "layer-3 tiles are walked in pairs");
-#pragma unroll 1
-        for (int u = 0; u < T3; u += TPS) {
+        auto l3_step = [&](int u, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             STAMP(40 + 4 * u);
             char* cur = RES ? smem + NC1 * Cfg::TB2 + u * Cfg::TB3 : (buf ? wt1 : wt0) + (u % UPT) * Cfg::TB3;
             char* nxt = buf ? wt0 : wt1;
@@ -727,6 +800,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     if (more_w3) dma_w3(u / UPT + 1, nxt); else if (more) dma_w2(0, nxt);
                 }
             }
+            float b3u = 0.f;
+            if constexpr (ROWS) b3u = p.b3[32 * u + l31];      // (requested here, used after the step's MFMAs)
             f32x16 acc, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
@@ -771,6 +846,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                             }
                         }
                         if constexpr (FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (FIRST) {
+                            if (t + 1 < T2) {
+                                if constexpr (!FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
+                                split_half(t + 1, m);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                     }
                 }
             }
@@ -784,9 +866,6 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 if constexpr (ROWS) {
                     // D3[point][channel]: this lane holds channel 32u + l31 of the points 8(r/4) + 4 half + r%4 -- one store
                     // instruction writes two 128-byte row segments
-                    float b3u = b3r[0];
-    #pragma unroll
-                    for (int uu = 1; uu < T3; ++uu) b3u = (uu == u) ? b3r[uu] : b3u;
                     float* orow = p.out + ((size_t)b * p.N + row0 + 4 * half) * p.ldo + 32 * u + l31;
                     const bool colok = valid && (32 * u + l31 < p.ncols);
                     float* ocm = p.out_cm ? p.out_cm + (size_t)b * p.out_cm_stride + (size_t)(32 * u + l31) * p.N + row0 + 4 * half : nullptr;
@@ -814,7 +893,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 }
             }
             STAMP(43 + 4 * u);
-        }
+        };
+        if constexpr (H2FUSE) l3_step(0, std::true_type{});
+#pragma unroll 1
+        for (int u = H2FUSE ? TPS : 0; u < T3; u += TPS) l3_step(u, std::false_type{});
         STAMP(37);
     }
 
