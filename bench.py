@@ -80,6 +80,7 @@ def parse(argv=None):
                          "(default), bf16x3 = fp32-class 3-plane bf16 split -- both pass the 1e-4 / exact-argmax parity bar, also on "
                          "checkpoints with hidden activations from 1e-4 to 1e+6 -- f32 = v_mfma_f32_32x32x2_f32, bf16 = reduced "
                          "precision (BASELINE.json config 3)")
+    ap.add_argument("--no-host-io", dest="no_host_io", action="store_true", help="skip the host-buffer (PCIe-inclusive) leg")
     ap.add_argument("--no-legs", "--no-f32-leg", dest="no_legs", action="store_true", help="skip the timing legs of the other arithmetic modes")
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -235,7 +236,7 @@ def live_pmc_traffic(a, timeout_s=300):
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     nsteps = 3
-    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site",
+    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site", "--no-host-io",
              "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud]
     tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
@@ -506,6 +507,7 @@ def run_rank(a) -> int:
     if L is not None:
         L.ev2h_profile_set(site1["tag"].encode(), ev.start, ev.stop, ev.n)
     dt = timed(a.steps)
+    local_dt = timed.local                   # this rank's own wall time of the timed region (later timed() calls overwrite timed.local)
     if L is not None:
         L.ev2h_profile_set(None, None, None, 0)
     main_kernel_ms = ev.elapsed_ms(a.steps) if ev is not None else []
@@ -517,7 +519,7 @@ def run_rank(a) -> int:
         timed(k2)
         L.ev2h_profile_set(None, None, None, 0)
         second_kernel_ms = ev2.elapsed_ms(k2)
-    rank_ms = [round(v / a.steps * 1e3, 3) for v in all_ranks(timed.local)]        # every rank's own wall time per step
+    rank_ms = [round(v / a.steps * 1e3, 3) for v in all_ranks(local_dt)]        # every rank's own wall time per step
     if a.stub:                             # launcher self-test: one more step on every rank whose gathered result rank 0 checks
         last = step()
         if not isinstance(last, dict):
@@ -580,6 +582,70 @@ def run_rank(a) -> int:
             leg_kernel_ms[prec] = evl.elapsed_ms(k)
             legs[prec] = {"value": round(gB * k / dtf, 2), "ms_per_step": round(dtf / k * 1e3, 3), "steps": k, "dtype": DTYPE[prec]}
         net.net.precision = a.precision
+
+    # host-side boundary: the same step with its input handed over in (pinned) HOST memory and its predictions returned to host
+    # memory, in stream order on the forward's stream (no copy/compute overlap: the pessimistic figure).  Reported beside `value`,
+    # never as `value`: the path's own boundary takes device buffers (TEHNet.forward(xyz) with xyz on the device, demo.py:24-33)
+    host_io = None
+    if not a.stub and not a.no_host_io and world == 1 and not a.collision:
+        try:
+            k = max(4, min(a.steps // 4, 24))
+            W = evdist.packed_width(N)
+            hx = xyz.detach().cpu().pin_memory()
+            dxs = [torch.empty_like(xyz) for _ in range(2)]
+            drows = [torch.empty(B, W, device=dev, dtype=torch.float32) for _ in range(2)]
+            hrows = [torch.empty(B, W, dtype=torch.float32).pin_memory() for _ in range(2)]
+            main = torch.cuda.current_stream(dev)
+            cin, cout = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+            def fwd(b):
+                net.net.fps_init = inits
+                with torch.no_grad():
+                    net.net(dxs[b], net.hands, rows=drows[b])
+
+            def in_order(i):
+                dxs[0].copy_(hx, non_blocking=True)
+                fwd(0)
+                hrows[0].copy_(drows[0], non_blocking=True)
+
+            ev_in = [torch.cuda.Event() for _ in range(2)]
+            ev_fwd = [torch.cuda.Event() for _ in range(2)]
+            ev_out = [torch.cuda.Event() for _ in range(2)]
+
+            def overlapped(i):
+                # input of step i and output of step i - 1 travel on their own streams under the forward of a neighbouring step
+                b = i & 1
+                with torch.cuda.stream(cin):
+                    cin.wait_event(ev_fwd[b])                  # the forward that last read dxs[b] (step i - 2)
+                    dxs[b].copy_(hx, non_blocking=True)
+                    ev_in[b].record(cin)
+                main.wait_event(ev_in[b])
+                main.wait_event(ev_out[b])                     # drows[b] of step i - 2 has left
+                fwd(b)
+                ev_fwd[b].record(main)
+                with torch.cuda.stream(cout):
+                    cout.wait_event(ev_fwd[b])
+                    hrows[b].copy_(drows[b], non_blocking=True)
+                    ev_out[b].record(cout)
+
+            def run(fn):
+                for i in range(2):
+                    fn(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(k):
+                    fn(i)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+
+            dt_io, dt_ov = run(in_order), run(overlapped)
+            host_io = {"value": round(B * k / dt_ov, 2), "unit": "event-windows/s", "ms_per_step": round(dt_ov / k * 1e3, 3), "steps": k,
+                       "in_stream_order": {"value": round(B * k / dt_io, 2), "ms_per_step": round(dt_io / k * 1e3, 3)},
+                       "bytes_h2d_per_step": int(hx.numel() * 4), "bytes_d2h_per_step": int(B * W * 4),
+                       "note": "pinned host input -> device, forward, packed predictions -> pinned host; `value`: copies on their own streams "
+                               "under the neighbouring steps' forwards (two buffers); in_stream_order: copy, forward, copy on one stream"}
+        except Exception as e:  # noqa: BLE001 -- never lose the throughput line to a side leg
+            host_io = {"error": f"{type(e).__name__}: {e}"}
 
     latency = None
     if not a.stub and not a.no_latency and world == 1:
@@ -651,6 +717,8 @@ def run_rank(a) -> int:
                 res["other_modes"] = legs
             if latency:
                 res["latency_ms"] = latency
+            if host_io:
+                res["pcie_inclusive"] = host_io
             if world == 1 and not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
         line = json.dumps(res)

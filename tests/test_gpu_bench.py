@@ -1,0 +1,79 @@
+"""bench.py's one-line contract on a real GPU: a short run of the real (non-stub) path, checked field by field.
+
+The CPU suite covers the launcher and the gather with `--stub`; the fields below only exist on the HIP path (HIP-event kernel
+times, the second launch site, the per-rank step times, the host-buffer leg), so they are checked here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(*extra, traffic=False):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--batch", "16", "--no-legs", "--no-latency",
+           "--no-cpu-baseline", *([] if traffic else ["--no-traffic"]), *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # ONE JSON line, and it is the last thing on stdout
+    assert r.stdout.strip().splitlines()[-1] == lines[0]
+    return json.loads(lines[0])
+
+
+def test_bench_line_fields_on_the_hip_path():
+    j = _run()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 12 and j["warmup"] == 2 and j["unit"] == "event-windows/s" and j["vs_baseline"] is None
+    assert "workload" in j["config"] and "model" not in j["config"]
+    # value = windows of the timed region / its wall time
+    assert abs(j["value"] - 16 * 1e3 / j["ms_per_step"]) <= 0.01 * j["value"]
+    # the per-rank step time is the timed region's (it once reported the last short side run's)
+    pr = j["ms_per_step_per_rank"]
+    assert len(pr["all"]) == 1 and abs(pr["max"] - j["ms_per_step"]) <= 0.05 * j["ms_per_step"], (pr, j["ms_per_step"])
+    for key in ("roofline", "roofline_second"):
+        r = j[key]
+        assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.0 < r["frac"] < 1.0 and r["kernel_ms"] > 0.0, r
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert j["roofline"]["launch_site"] != j["roofline_second"]["launch_site"]
+    io = j["pcie_inclusive"]
+    assert "error" not in io, io
+    assert 0.0 < io["value"] <= 1.10 * j["value"] and 0.0 < io["in_stream_order"]["value"] <= 1.10 * j["value"], (io, j["value"])
+    assert io["bytes_h2d_per_step"] == 16 * 4 * 2048 * 4
+
+
+def test_bench_forced_single_rank_rccl_path():
+    """the multi-GPU code path (process group, gather pipeline, self-checks) with one rank"""
+    env_key = "EV2H_BENCH_FORCE_DIST"
+    old = os.environ.get(env_key)
+    os.environ[env_key] = "1"
+    try:
+        j = _run("--no-host-io")
+    finally:
+        if old is None:
+            os.environ.pop(env_key, None)
+        else:
+            os.environ[env_key] = old
+    assert j["config"]["backend"] == "nccl (RCCL)" and j["config"]["world_size_seen"] == 1
+    sc = j["multi_gpu_selfcheck"]
+    assert sc["gather_ms"] >= 0.0 and len(sc["two_stream_gain_per_rank"]) == 1
+    assert abs(j["ms_per_step_per_rank"]["max"] - j["ms_per_step"]) <= 0.05 * j["ms_per_step"]
+
+
+def test_bench_live_hbm_traffic_counts_the_forwards_only():
+    """the rocprofv3 PMC child passes must see the step's forwards and nothing else (a side leg's extra forwards once inflated the
+    per-step bytes five-fold): per window the step moves ~33 MB at B = 256; at B = 16 the 18 MB of weights are shared by fewer windows"""
+    j = _run(traffic=True)
+    hbm = j["hbm"]
+    if "measured in this run" not in str(hbm.get("source", "")):
+        pytest.skip(f"live PMC passes unavailable on this box: {hbm.get('source')}")
+    per_window = hbm["bytes_per_step"] / 16
+    assert 10e6 < per_window < 90e6, per_window
+    t = j["roofline"]["traffic"]
+    assert t is None or 1e6 < t < 400e6, t
