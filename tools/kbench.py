@@ -72,6 +72,8 @@ def bench_gemm(B=256, N=2048, precision="f32", rows=128):
                                   (R, 256, 256, 1, "cls0"), (R, 4, 256, 1, "cls4"), (R, 160, 8, 1, "P1a"), (R, 256, 8, 1, "P1m"),
                                   (B * 512, 256, 576, 1, "fp2.0"), (B * 512, 256, 320, 1, "P1b"), (B * 128, 256, 520, 1, "sa3.0"),
                                   (B * 128, 1024, 512, 1, "sa3.2")]:
+        if os.environ.get("KBENCH_GEMM_ONLY") and tag not in os.environ["KBENCH_GEMM_ONLY"].split(","):
+            continue
         X = torch.randn(M, K, device="cuda")
         W = torch.randn(Nn, K * taps, device="cuda") * (K * taps) ** -0.5
         b = torch.randn(Nn, device="cuda")
