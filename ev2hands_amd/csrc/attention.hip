@@ -245,6 +245,18 @@ extern "C" size_t ev2h_attn_sim_folded_scratch(int B, int N) {
     return (size_t)B * ceil_div(N, ZS_ROWS) * 12 * 512;
 }
 
+// Second half of ev2h_attn_sim_folded alone, for partials that the first query convolution's own epilogue produced
+// (gemm_bf16.hip: zsum_epilogue; rows_per_partial = 128 there): zpart [B][N / rows_per_partial][12][512].  Internal (forward.hip).
+int ev2h_attn_simfold_partials(const float* zpart, int rows_per_partial, const float* logits_pm, int B, int N, const float* w4t_left,
+                               const float* w4t_right, const float* b4_left, const float* b4_right, float* sim, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(zpart && logits_pm && w4t_left && w4t_right && b4_left && b4_right && sim && B > 0 && N > 0 && rows_per_partial > 0 &&
+                   N % rows_per_partial == 0);
+    attn_simfold_kernel<<<dim3(B, 2), 1024, 0, (hipStream_t)stream>>>(zpart, N / rows_per_partial, (const float4*)logits_pm, N, w4t_left, w4t_right,
+                                                                      b4_left, b4_right, sim);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
 extern "C" int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, int ldq, int B, int N, const float* w4t_left,
                                     const float* w4t_right, const float* b4_left, const float* b4_right, float* scratch, float* sim,
                                     ev2h_stream_t stream) {

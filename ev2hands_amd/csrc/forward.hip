@@ -127,6 +127,11 @@ static SideCtx* side_ctx() {     // the current device's side stream, or nullptr
 }
 
 // ---------------------------------------------------------------------------------------- small kernels
+// internal entry points of other translation units (not part of the C ABI)
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, ev2h_stream_t stream);
+int ev2h_attn_simfold_partials(const float* zpart, int rows_per_partial, const float* logits_pm, int B, int N, const float* w4t_left,
+                               const float* w4t_right, const float* b4_left, const float* b4_right, float* sim, ev2h_stream_t stream);
+
 namespace {
 
 // dst[row][col..col+7] = (x, y, z, 0, 0, 0, 0, 0): the raw-xyz columns of a group-all input
@@ -228,7 +233,7 @@ static void build_layout(Layout& L, int B, int N) {
     L.add("logits_pm", R * 4);
     L.add("q1", R * 512);
     if (attn_unfolded()) L.add("q2", 2 * R * 256);
-    L.add("zpart", ev2h_attn_sim_folded_scratch(B, N));
+    L.add("zpart", std::max(ev2h_attn_sim_folded_scratch(B, N), (size_t)B * ceil_div(N, 128) * 12 * 512));     // (fused form: one partial per 128 rows)
     L.add("sim", b * 2 * 4 * 256);
     L.add("hf8", 2 * R * 8);
     L.add("nn2_idx", b * 512 * 3);
@@ -658,12 +663,35 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     // (q1's range record is only needed by the unfolded second convolution: the folded form reads q1 in fp32)
-    prof_begin("qconv0", st);
-    RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, attn_unfolded() ? rg(R_L0, N, R_Q1, N) : rg(R_L0, N), nullptr, 0, 0, 3, N));
-    prof_end("qconv0", st);
+    // [r4] BF16 / F16X2: q1 is NOT WRITTEN -- the GEMM's epilogue forms the attention's key-weighted sums of its own tile
+    // (gemm_bf16.hip: zsum_epilogue), which makes the logits its input: the classifier is waited for first.
+    // EV2H_ATTN_UNFUSED_ZSUM=1: A/B switch (q1 to memory, attn_zsum_kernel reads it back).
+    const bool unfolded = attn_unfolded();
+    static const bool unfused_zsum = getenv("EV2H_ATTN_UNFUSED_ZSUM") != nullptr;
+    bool zsum_fused = false;
+    if (!unfolded && !unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws && N % 128 == 0) {
+        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));          // logits ready
+        const Rng r0 = rg(R_L0, N);
+        ev2h_gemm_desc d{};
+        d.x_amax = r0.xa; d.x_amax2 = r0.xa2; d.x_group_rows = r0.xg;
+        d.X = ws.f("l0"); d.ldx = 256; d.W = w->qconv0.W; d.ldw = w->qconv0.ldw;
+        d.M = R; d.N = w->qconv0.O; d.K = w->qconv0.K;
+        d.bias = w->qconv0.b; d.relu = 1; d.post_scale = w->qconv0.post_scale; d.post_shift = w->qconv0.post_shift;
+        d.taps = 3; d.rows_per_seq = N; d.precision = prec; d.Ws = w->qconv0.Ws; d.ws_tile_rows = w->qconv0.ws_tile_rows;
+        d.w_unscale = w->qconv0.w_unscale;
+        prof_begin("qconv0", st);
+        const int rc = ev2h_gemm_bf16_zsum(&d, ws.f("logits_pm"), ws.f("zpart"), st);
+        prof_end("qconv0", st);
+        if (rc == EV2H_OK) zsum_fused = true;
+        else if (rc != EV2H_ERR_ARG) return rc;
+    }
+    if (!zsum_fused) {
+        prof_begin("qconv0", st);
+        RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, attn_unfolded() ? rg(R_L0, N, R_Q1, N) : rg(R_L0, N), nullptr, 0, 0, 3, N));
+        prof_end("qconv0", st);
+    }
     // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
     // over the points (ev2h_attn_sim_folded): q2 is never formed
-    const bool unfolded = attn_unfolded();
     if (unfolded) {
         for (int h = 0; h < 2; ++h)
             RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
@@ -671,6 +699,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));              // logits ready
     if (unfolded) {
         RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
+    } else if (zsum_fused) {
+        RUN(ev2h_attn_simfold_partials(ws.f("zpart"), 128, ws.f("logits_pm"), B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
+                                       ws.f("sim"), st));
     } else {
         RUN(ev2h_attn_sim_folded(ws.f("logits_pm"), ws.f("q1"), 512, B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
                                  ws.f("zpart"), ws.f("sim"), st));

@@ -15,6 +15,7 @@ namespace {
 
 
 constexpr int GB_BM = 128, GB_BN = 128, GB_BK = 32, GB_THREADS = 512;
+constexpr int GO_THREADS_ = 256, GB_BN_ = 128;      // (occupancy kernel: threads, tile columns -- used by zsum_epilogue above its definition)
 
 struct GemmBP {
     const float* X; int ldx;
@@ -33,6 +34,9 @@ struct GemmBP {
     float* y_scale; float y_bound_w, y_bound_b;                           // out: Y is stored times the power of two that keeps
                                                                           // (y_bound_w * max|X| + y_bound_b) * s below 2^15
     int tiles_n; int nblk;
+    // TAP3 occupancy kernel only: the attention's key-weighted column sums (attention.hip: Z[c][t][i]) formed in the epilogue instead of
+    // storing Y -- zs_key = logits, point-major [M][4]; zs_out = chunk partials [M / 128][12][N] (see zsum_epilogue)
+    const float4* zs_key; float* zs_out;
 };
 
 template <int NS>
@@ -443,6 +447,131 @@ int launch_gw(const GemmBP& p, const char* Ws, hipStream_t st) {
     return EV2H_OK;
 }
 
+// ---------------------------------------------------------------------------------------- q1 never written
+// Epilogue of the first query convolution when only the attention consumes it (TEHNet.py:150-166, 13-27; attention.hip): the second
+// convolution is folded behind the attention's sum over the points, so q1 = BN(ReLU(conv(l0))) enters only through
+//     Z[c][t][i] = sum_n key[c][n] q1[i][n + t - 1]            (key = segmentation logits, zero outside the window).
+// A tile holds 128 rows n of 128 columns i in its accumulators -- in D layout exactly the B operand of a
+// [12 (class, tap) rows] x [k = 128 tile rows] x [128 columns] product (a lane's registers 8 kb .. 8 kb + 7 are the 8 k slots of
+// k-block kb; the key rows are gathered in that slot order) -- so the tile's contribution to Z is 8 more MFMAs per plane product
+// and wave (+4 % on the tile's own), and the 1.07 GB of q1 per 256 windows are neither written nor read again.  The tile's
+// 12 x 128 partial goes to zpart[(window, tile)][12][512]; attn_simfold_kernel adds the tiles in order (fixed order, no atomics:
+// reproducible and batch-independent, like the two-pass form).  F16X2: q1 and the keys are scaled by powers of two chosen from the
+// wave's / the tile's own maxima (exact), the partial is multiplied back.
+template <int NS>
+__device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][2], int m0, int wm, int wn, int n0, char* smem, int tid) {
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    constexpr int KLD = 136;
+    float* keyL = reinterpret_cast<float*>(smem);             // [4][KLD]: key[c][m0 - 1 + i], i = 0..129
+    float* red = keyL + 4 * KLD;                               // [12][128]: the partial of the lower 64 rows' waves
+    __syncthreads();                                           // the operand tiles are dead
+    const int pos0 = m0 % p.rows_per_seq;
+    for (int i = tid; i < GB_BM + 2; i += GO_THREADS_) {
+        const int pos = pos0 - 1 + i;
+        const long row = (long)m0 - 1 + i;
+        float4 k = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos >= 0 && pos < p.rows_per_seq && row < p.M) k = p.zs_key[row];
+        keyL[i] = k.x; keyL[KLD + i] = k.y; keyL[2 * KLD + i] = k.z; keyL[3 * KLD + i] = k.w;
+    }
+    // q1 values of this wave: bias, ReLU, BN affine -- the store epilogue's arithmetic
+    const float* bias = p.bias;
+    float bj[2], sj[2], tj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool okc = col < p.N;
+        bj[j] = (bias && okc) ? bias[col] : 0.f;
+        sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
+        tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
+    }
+    float cx = p.w_unscale;
+    if (NS == 2 && p.x_amax) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
+    float amf = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + mfma_row(r, half);
+                float v = acc[i][j][r] * cx + bj[j];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
+                if (row >= p.M) v = 0.f;
+                acc[i][j][r] = v;
+                amf = fmaxf(amf, fabsf(v));
+            }
+    __syncthreads();                                           // the key tile is complete
+    float sq = 1.f, sk = 1.f;
+    if constexpr (NS == 2) {
+        sq = f16x2_scale(wave_max_u32_dpp(__float_as_uint(amf)));
+        float km = 0.f;
+        for (int i = lane; i < 4 * KLD; i += 64) km = fmaxf(km, (i % KLD) < GB_BM + 2 ? fabsf(keyL[i]) : 0.f);
+        sk = f16x2_scale(wave_max_u32_dpp(__float_as_uint(km)));
+    }
+    // A operand: lane (m = l31 < 12: class m / 3, tap m % 3; the other lanes repeat m = 0 and their D rows are not used), half h:
+    // k slot e of k-block (i, kb) is the tile row wm * 64 + 32 i + mfma_row(8 kb + e, h), paired with key row n - t + 1
+    const int m = l31 < 12 ? l31 : 0, kc = m / 3, kt = m - 3 * kc;
+    const float* kr = keyL + kc * KLD + 2 - kt + wm * 64;
+    f32x16 z[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[j][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            u32x4 ap[NS];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float a0 = kr[32 * i + mfma_row(8 * kb + 2 * w, half)] * sk, a1 = kr[32 * i + mfma_row(8 * kb + 2 * w + 1, half)] * sk;
+                unsigned o[NS];
+                split_planes<NS>(a0, a1, o);
+#pragma unroll
+                for (int s_ = 0; s_ < NS; ++s_) ap[s_][w] = o[s_];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 bq[NS];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    unsigned o[NS];
+                    split_planes<NS>(acc[i][j][8 * kb + 2 * w] * sq, acc[i][j][8 * kb + 2 * w + 1] * sq, o);
+#pragma unroll
+                    for (int s_ = 0; s_ < NS; ++s_) bq[s_][w] = o[s_];
+                }
+#pragma unroll
+                for (int q = 0; q < Planes<NS>::NPROD; ++q) z[j] = mfma_planes<NS>(ap[Planes<NS>::A[q]], bq[Planes<NS>::B[q]], z[j]);
+            }
+        }
+    // D rows: register r of half h is (class, tap) row mfma_row(r, h): rows 0..3 and 8..11 in the lower half-wave, 4..7 in the upper
+    const float inv = pow2_inverse(sq) * pow2_inverse(sk);
+    const int ch = pos0 / GB_BM, nch = p.rows_per_seq / GB_BM;
+    const long bw = m0 / p.rows_per_seq;
+    float* zp = p.zs_out + ((size_t)bw * nch + ch) * 12 * p.N;
+    if (wm == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int mr = mfma_row(r, half);
+                if (mr < 12) red[mr * GB_BN_ + wn * 64 + j * 32 + l31] = z[j][r] * inv;
+            }
+    }
+    __syncthreads();
+    if (wm == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int mr = mfma_row(r, half);
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                if (mr < 12 && col < p.N) zp[(size_t)mr * p.N + col] = z[j][r] * inv + red[mr * GB_BN_ + wn * 64 + j * 32 + l31];
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------- occupancy variant
 // 128 x 128 x 32 tiles, 4 waves (2 x 2, each 64 x 64), ONE LDS buffer (53 KB at NS = 3) so that three
 // independent workgroups share a CU: while one sits at its barrier or stages the next K tile, the other two
@@ -675,6 +804,9 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         }
     }
 
+    if constexpr (TAP3 && NS <= 2) {          // (BF16X3 keeps the two-pass form: its instantiation would spill)
+        if (p.zs_out) { zsum_epilogue<NS>(p, acc, m0, wm, wn, n0, smem, tid); return; }
+    }
     gemm_epilogue<NS, 2, 2, false>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
 }
 
@@ -830,6 +962,32 @@ int ev2h_gemm_tile_geometry(int ns, int out[2]) {
     out[0] = ns == 1 ? GBCfg<1>::RS : ns == 2 ? GBCfg<2>::RS : GBCfg<3>::RS;
     out[1] = GB_BK;
     return EV2H_OK;
+}
+
+// The first query convolution with the attention's key-weighted sums as its output (zsum_epilogue): d describes the k = 3 GEMM as for
+// ev2h_gemm (d->Y unused), key_pm = logits point-major [M][4], zpart [M / 128][12][N].  Internal (forward.hip); returns
+// EV2H_ERR_ARG for shapes the tap kernel does not take -- the caller then runs the two-pass form.
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, ev2h_stream_t stream) {
+    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && d->precision != EV2H_PREC_F32 && d->K % GB_BK == 0 && d->rows_per_seq % GB_BM == 0 &&
+          d->M % d->rows_per_seq == 0 && d->N % GO_BN == 0 && key_pm && zpart))
+        return EV2H_ERR_ARG;
+    GemmBP p{};
+    p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = nullptr; p.ldy = 0;
+    p.M = d->M; p.N = d->N; p.taps = 3; p.Kc = d->K; p.K = d->K * 3;
+    p.rows_per_seq = d->rows_per_seq;
+    p.bias = d->bias; p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
+    p.w_unscale = d->w_unscale > 0.f ? d->w_unscale : 1.f;
+    p.x_group_rows = p.y_group_rows = 1;
+    if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+        p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
+        if (p.x_group_rows % GB_BM != 0 || p.x_group_rows % d->rows_per_seq != 0) return EV2H_ERR_ARG;
+    }
+    p.zs_key = reinterpret_cast<const float4*>(key_pm); p.zs_out = zpart;
+    p.tiles_n = d->N / GO_BN;
+    p.nblk = (d->M / GB_BM) * p.tiles_n;
+    if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true>(p, (const char*)d->Ws, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16) return launch_go_t<1, true>(p, (const char*)d->Ws, (hipStream_t)stream);
+    return EV2H_ERR_ARG;
 }
 
 // called by ev2h_gemm when d->precision != EV2H_PREC_F32 (arguments already validated there)
