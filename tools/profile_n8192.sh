@@ -13,5 +13,5 @@ python tools/rocpd_summary.py $(ls $O/${TAG}_kt8k/*/*.db $O/${TAG}_kt8k/*.db 2>/
 unset EV2H_TWO_STREAMS
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pf8k -o p -- $PY bench.py --steps 2 --warmup 1 $ARGS > $O/${TAG}_pf8k.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pw8k -o p -- $PY bench.py --steps 2 --warmup 1 $ARGS > $O/${TAG}_pw8k.log 2>&1
-python tools/pmc_traffic.py $(ls $O/${TAG}_pf8k/*/*.db $O/${TAG}_pf8k/*.db 2>/dev/null | head -1) $(ls $O/${TAG}_pw8k/*/*.db $O/${TAG}_pw8k/*.db 2>/dev/null | head -1) f16x2 $O/${TAG}_pmc_hbm_traffic_n8192_f16x2.json ${TAG#r} 3 > /dev/null 2>&1
+python tools/pmc_traffic.py $(ls $O/${TAG}_pf8k/*/*.db $O/${TAG}_pf8k/*.db 2>/dev/null | head -1) $(ls $O/${TAG}_pw8k/*/*.db $O/${TAG}_pw8k/*.db 2>/dev/null | head -1) f16x2 $O/${TAG}_pmc_hbm_traffic_n8192_f16x2.json ${TAG//[^0-9]/} 3 > /dev/null 2>&1
 rm -rf $O/${TAG}_kt8k $O/${TAG}_pf8k $O/${TAG}_pw8k

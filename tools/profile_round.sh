@@ -26,7 +26,7 @@ unset EV2H_TWO_STREAMS
 for prec in f16x2 bf16 f32; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch_$prec -o p -- $PY $SMALL --precision $prec > $O/${TAG}_pmc_fetch_$prec.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_write_$prec -o p -- $PY $SMALL --precision $prec > $O/${TAG}_pmc_write_$prec.log 2>&1
-  python tools/pmc_traffic.py $(ls $O/${TAG}_pmc_fetch_$prec/*/*.db $O/${TAG}_pmc_fetch_$prec/*.db 2>/dev/null | head -1) $(ls $O/${TAG}_pmc_write_$prec/*/*.db $O/${TAG}_pmc_write_$prec/*.db 2>/dev/null | head -1) $prec $O/${TAG}_pmc_hbm_traffic_$prec.json ${TAG#r} 3 > /dev/null 2>&1
+  python tools/pmc_traffic.py $(ls $O/${TAG}_pmc_fetch_$prec/*/*.db $O/${TAG}_pmc_fetch_$prec/*.db 2>/dev/null | head -1) $(ls $O/${TAG}_pmc_write_$prec/*/*.db $O/${TAG}_pmc_write_$prec/*.db 2>/dev/null | head -1) $prec $O/${TAG}_pmc_hbm_traffic_$prec.json ${TAG//[^0-9]/} 3 > /dev/null 2>&1
 done
 for prec in f16x2 bf16; do
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/${TAG}_pmc_sq_a_$prec -o p -- $PY $SMALL --precision $prec > $O/${TAG}_pmc_sq_a_$prec.log 2>&1
