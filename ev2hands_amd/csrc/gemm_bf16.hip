@@ -546,7 +546,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
             }
         }
     // D rows: register r of half h is (class, tap) row mfma_row(r, h): rows 0..3 and 8..11 in the lower half-wave, 4..7 in the upper
-    const float inv = pow2_inverse(sq) * pow2_inverse(sk);
+    const float iq = pow2_inverse(sq), ik = pow2_inverse(sk);      // applied one after the other: their product may leave the fp32 range when the true sum does not
     const int ch = pos0 / GB_BM, nch = p.rows_per_seq / GB_BM;
     const long bw = m0 / p.rows_per_seq;
     float* zp = p.zs_out + ((size_t)bw * nch + ch) * 12 * p.N;
@@ -556,7 +556,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int mr = mfma_row(r, half);
-                if (mr < 12) red[mr * GB_BN_ + wn * 64 + j * 32 + l31] = z[j][r] * inv;
+                if (mr < 12) red[mr * GB_BN_ + wn * 64 + j * 32 + l31] = (z[j][r] * iq) * ik;
             }
     }
     __syncthreads();
@@ -567,7 +567,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
             for (int r = 0; r < 8; ++r) {
                 const int mr = mfma_row(r, half);
                 const int col = n0 + wn * 64 + j * 32 + l31;
-                if (mr < 12 && col < p.N) zp[(size_t)mr * p.N + col] = z[j][r] * inv + red[mr * GB_BN_ + wn * 64 + j * 32 + l31];
+                if (mr < 12 && col < p.N) zp[(size_t)mr * p.N + col] = (z[j][r] * iq) * ik + red[mr * GB_BN_ + wn * 64 + j * 32 + l31];
             }
     }
 }
