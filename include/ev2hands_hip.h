@@ -283,7 +283,10 @@ int ev2h_attn_sim(const float* logits_pm, const float* query_pm, int ldq, size_t
  * convolution per hand; exact fp32 fma chains in a fixed order (no atomics).  A re-association of the reference's sum: results
  * agree to fp32 rounding, not bit for bit.
  * q1_pm [B*N][ldq]: hand h's 256 channels at column h*256.  w4t_* [768][256] = W transposed (row t*256 + i, column d), b4_* [256].
- * scratch: ev2h_attn_sim_folded_scratch(B, N) floats. */
+ * scratch: ev2h_attn_sim_folded_scratch(B, N) floats.
+ * (ev2h_forward in BF16 / F16X2 on windows of a multiple of 128 points does not call this operator for the Z sums: the first query
+ * convolution's GEMM forms them in its epilogue and q1 is never written -- csrc/gemm_bf16.hip: zsum_epilogue; EV2H_ATTN_UNFUSED_ZSUM=1
+ * restores the operator form.  Same contract, different summation order: 5e-7 apart in F16X2.) */
 size_t ev2h_attn_sim_folded_scratch(int B, int N);
 int ev2h_attn_sim_folded(const float* logits_pm, const float* q1_pm, int ldq, int B, int N, const float* w4t_left,
                          const float* w4t_right, const float* b4_left, const float* b4_right, float* scratch, float* sim,
