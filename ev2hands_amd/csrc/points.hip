@@ -338,9 +338,14 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t st = (hipStream_t)stream;
     const float4* p = (const float4*)pts4;
+    static const bool no_wide = getenv("EV2H_FPS_NO_WIDE") != nullptr;
     if (N > 2048 && N <= 8192) {   // > 32 KiB of points: raise the dynamic-LDS limit once
         static PerDevice attr_set{};
         EV2H_ONCE_PER_DEVICE(attr_set,
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8, 512, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
+            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16, 512, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<32>),
@@ -350,6 +355,11 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     else if (N <= 512) fps_kernel<2><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 1024) fps_kernel<4><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 2048) fps_kernel<8><<<grid, 256, lds, st>>>(p, N, jobs);
+    // N > 2048: the staged points (64 / 128 KB) leave two / one workgroup per CU, and with 16 / 32 points per thread the distance update
+    // is most of a sampling step -- eight waves per window halve it (N = 2048 keeps four: there the exchange and the barrier dominate
+    // and sixteen waves measured slower).  Same maxima, same tie-break: identical indices.  EV2H_FPS_NO_WIDE=1: A/B.
+    else if (N <= 4096 && !no_wide) fps_kernel<8, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
+    else if (N <= 8192 && !no_wide) fps_kernel<16, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
     else if (N <= 4096) fps_kernel<16><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 8192) fps_kernel<32><<<grid, 256, lds, st>>>(p, N, jobs);
     else if (N <= 16384) fps_kernel<16, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);      // beyond the LDS-resident sizes
