@@ -74,22 +74,44 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* src = pts4 + (size_t)b * N;
 
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
+    // REG_PTS: a thread keeps its points' coordinates in registers.  Not at 32 points per thread in the 1024-thread form (N > 16 384):
+    // 4 x 32 values do not fit the 128 registers of a 16-wave workgroup (the instantiation spilled 208 bytes into the serial loop) --
+    // there only the running minima stay in registers and the coordinates are read again every step (coalesced, L2-resident).
+#ifdef EV2H_FPS_REG_PTS_ALL      // (build switch for the A/B: the old form, spilling)
+    constexpr bool REG_PTS = true;
+#else
+    constexpr bool REG_PTS = !(PPT >= 32 && THREADS >= 1024);
+#endif
+    float px[REG_PTS ? PPT : 1], py[REG_PTS ? PPT : 1], pz[REG_PTS ? PPT : 1], md[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int p = j * THREADS + tid;
-        float4 v = (p < N) ? src[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (LDS_PTS && p < N) spts[p] = v;
-        px[j] = v.x; py[j] = v.y; pz[j] = v.z;
+        if constexpr (REG_PTS || LDS_PTS) {
+            float4 v = (p < N) ? src[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (LDS_PTS && p < N) spts[p] = v;
+            if constexpr (REG_PTS) { px[j] = v.x; py[j] = v.y; pz[j] = v.z; }
+        }
         md[j] = 1e10f;
     }
     __syncthreads();
+    int tid_v = tid;          // (!REG_PTS: laundered once per sampling step, so that the 32 load offsets are not hoisted out of the loop and spilled)
+    auto coord = [&](int j, float& x, float& y, float& z) {
+        if constexpr (REG_PTS) { x = px[j]; y = py[j]; z = pz[j]; }
+        else {
+            // (clamped index instead of a guarded load: no branch per point, one 32-bit offset per load; lanes past the window's end
+            //  never enter the argmax -- the key comparison has its own p < N)
+            const unsigned pc = (unsigned)min(j * THREADS + tid_v, N - 1);
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src) + (size_t)pc * sizeof(float4));
+            x = v.x; y = v.y; z = v.z;
+        }
+    };
 
     int far = (int)jobs.init[job][b];
     int32_t* oidx = jobs.idx[job] + (size_t)b * S;
     float4* octr = jobs.ctr[job] + (size_t)b * S;
 
     for (int i = 0; i < S; ++i) {
+        if constexpr (!REG_PTS) asm volatile("" : "+v"(tid_v));
         const float4 c = LDS_PTS ? spts[far] : src[far];
         if (tid == 0) { oidx[i] = far; octr[i] = c; }
         unsigned long long best = 0ull;
@@ -99,7 +121,10 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__
             const f32x2 cx = {c.x, c.x}, cy = {c.y, c.y}, cz = {c.z, c.z};
 #pragma unroll
             for (int j = 0; j < PPT; j += 2) {
-                const f32x2 dx = f32x2{px[j], px[j + 1]} - cx, dy = f32x2{py[j], py[j + 1]} - cy, dz = f32x2{pz[j], pz[j + 1]} - cz;
+                float x0, y0, z0, x1, y1, z1;
+                coord(j, x0, y0, z0);
+                coord(j + 1, x1, y1, z1);
+                const f32x2 dx = f32x2{x0, x1} - cx, dy = f32x2{y0, y1} - cy, dz = f32x2{z0, z1} - cz;
                 const f32x2 d = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -109,12 +134,17 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__
                         ((unsigned long long)__float_as_uint(md[j + e]) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p);
                     if (p < N && key > best) best = key;
                 }
+                if constexpr (!REG_PTS) {
+                    if ((j & 6) == 6) __builtin_amdgcn_sched_barrier(0);      // eight coordinate loads in flight at a time, not all 32
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
                 const int p = j * THREADS + tid;
-                const float dx = __fsub_rn(px[j], c.x), dy = __fsub_rn(py[j], c.y), dz = __fsub_rn(pz[j], c.z);
+                float x0, y0, z0;
+                coord(j, x0, y0, z0);
+                const float dx = __fsub_rn(x0, c.x), dy = __fsub_rn(y0, c.y), dz = __fsub_rn(z0, c.z);
                 const float d = sqnorm3(dx, dy, dz);
                 if (d < md[j]) md[j] = d;
                 // key: larger distance first, then smaller index (torch.max returns the first maximum)
