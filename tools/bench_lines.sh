@@ -9,5 +9,6 @@ python bench.py --precision bf16 $Q 2>/dev/null | tail -1 > $O/${TAG}_bench_line
 python bench.py --cloud U $Q 2>/dev/null | tail -1 > $O/${TAG}_bench_line_U.json
 python bench.py --points 8192 --batch 128 --steps 100 $Q 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192.json
 python bench.py --points 8192 --batch 128 --steps 100 --collision $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_collision.json
+python bench.py --points 8192 --batch 128 --steps 60 --collision --collision-mesh soup $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_collision_soup.json
 EV2H_BENCH_FORCE_DIST=1 python bench.py $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_force_dist.json
 for f in $O/${TAG}_bench_line_*.json; do python -c "import json,sys; j=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', j['value'], j['ms_per_step'], j.get('pcie_inclusive',{}).get('value'), j['roofline']['frac'])"; done
