@@ -103,7 +103,6 @@ struct SaBCfg {
     static constexpr int RES_W = (NC1 * TB2 + T3 * TB3 + 1023) / 1024 * 1024;
     static constexpr int RES_LDS_BYTES = RES_W + SMALL;
     static constexpr bool FITS_RESIDENT = RES_LDS_BYTES <= 160 * 1024 && C1 >= 64;   // (the 32-32-64 MLP is faster streamed: several small workgroups per CU)
-    static constexpr bool PREFETCH_P1 = true;   // gathered P1 rows of the next 32-channel chunk are loaded one chunk ahead
     // F16X2 with 1..4 channels left over after the last full 32-channel tile (C2 = 196: channels 192..195): the three plane
     // products of those channels share MFMAs instead of taking three each (csrc/pack.hip builds the matching images):
     //  * layer 2, last tile: rows 8..11 of the tile's HIGH-plane image hold the LOW plane of rows 0..3, so (A = high image,
@@ -380,7 +379,6 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         // a lane's j4-th float4 of a 32-channel chunk: channels 8 j4 + 4 half + (0..3) -- the D layout of a 32 x 32 MFMA, so that layer 1
         // may come from the matrix pipe (BF16, F16X2 feature mode) or from the VALU without changing the W2 images (W2PERM)
         auto qi = [&](int j4) { return 2 * j4 + half; };
-        constexpr int HOFF = 0;
         const float4* prow = nullptr;
         const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
         float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
@@ -404,14 +402,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                                         : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
         if constexpr (DIRECT) {
-            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp + HOFF * half);
+            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp);
             fetch(0);
             blend();
         } else if constexpr (ROWS) {
             const size_t gr = ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * 3;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                trow[j] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + p.nn_idx[gr + j]) * p.ldp + HOFF * half);
+                trow[j] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + p.nn_idx[gr + j]) * p.ldp);
                 tw[j] = p.nn_w[gr + j];
             }
             fetch(0);
@@ -728,7 +726,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_nxt) * p.ldf);
                     f0_cur = fr[0]; f1_cur = fr[1];
                 } else {
-                    const float4* pn = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx_nxt) * p.ldp + HOFF * half);
+                    const float4* pn = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx_nxt) * p.ldp);
 #pragma unroll
                     for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(pn + qi(j4));
                 }
