@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libev2hands_hip.so")
+# EV2H_LIB_PATH: another BUILD of the same library (tools/asan_host.sh: host code under AddressSanitizer / UBSan); never a fallback --
+# a missing file still raises
+LIB_PATH = os.environ.get("EV2H_LIB_PATH") or os.path.join(_HERE, "libev2hands_hip.so")
 
 vp = C.c_void_p
 ci = C.c_int
