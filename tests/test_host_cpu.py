@@ -113,6 +113,19 @@ def test_no_cpu_fallback():
         net(torch.zeros(1, 5, 256))          # wrong channel count is reported before anything runs
 
 
+def test_lib_path_override_is_not_a_fallback():
+    """EV2H_LIB_PATH selects another BUILD of the library (tools/asan_host.sh); a path that does not exist must raise, not fall back to
+    the in-tree build or to anything on the CPU"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from ev2hands_amd import _lib\ntry:\n    _lib.lib()\nexcept _lib.Ev2hError as e:\n    print('RAISED', e)\n"
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, EV2H_LIB_PATH="/nonexistent/libev2hands_hip.so"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert "RAISED" in r.stdout and "/nonexistent/libev2hands_hip.so is missing" in r.stdout, r.stdout
+
+
 def test_packed_weight_layouts():
     from ev2hands_amd.pack import PackedWeights
     sd = synth.synth_state_dict(5, 3)
