@@ -58,10 +58,10 @@ def launch_sites(N):
     128-196-256 of enc.sa2 branch 1 (independent of N: 128 centroids x 128 neighbours) and the k = 3 query convolution of both
     hands (one GEMM, [N x 768] x [768 x 512] per window, TEHNet.py:150-153).  At N = 2048 the first is larger (1 233 vs 805 MMAC
     per window), at BASELINE config 5's N = 8192 the second (3 221 MMAC).  The DOMINANT one for the workload is the `roofline`
-    entry; the other is reported as `roofline_second`."""
-    sa = {"tag": "sa2.1", "mac_per_window": PROFILED_MAC_PER_WINDOW, "trace_key": "128, 196, 256",
+    entry; the other is reported as `roofline_second`.  (Which dispatches of a trace belong to a site: site_dispatch_values.)"""
+    sa = {"tag": "sa2.1", "mac_per_window": PROFILED_MAC_PER_WINDOW,
           "name": "sa_mlp_max<128,196,256> (sa2.1, K=128"}
-    qc = {"tag": "qconv0", "mac_per_window": N * 768 * 512, "trace_key": "gemm_nt_bf16_occ_kernel<2, true>",
+    qc = {"tag": "qconv0", "mac_per_window": N * 768 * 512,
           "name": f"gemm_nt k=3 query convolution, both hands (qconv0, M={N}/window K=3x256 N=512"}
     return (sa, qc) if sa["mac_per_window"] >= qc["mac_per_window"] else (qc, sa)
 
@@ -222,6 +222,21 @@ def committed_pmc_traffic(precision="f32"):
         return None, None
 
 
+def profiled_interpreter():
+    """The program that follows `rocprofv3 ... --`.  It must be the interpreter ITSELF (the profiler's preloaded library has
+    initialised the GPU, so any env / shell / launcher hop that re-execs is refused on this pool).  A symlink is not an exec hop, and
+    resolving it would leave a virtualenv (the base interpreter has no pyvenv.cfg, hence no venv site-packages): sys.executable is
+    used as it is unless it is a script shim (starts with `#!`), in which case the ELF behind it is taken."""
+    exe = sys.executable
+    try:
+        with open(exe, "rb") as f:
+            if f.read(2) == b"#!":
+                return os.path.realpath(getattr(sys, "_base_executable", exe) or exe)
+    except OSError:
+        pass
+    return exe
+
+
 def live_pmc_traffic(a, timeout_s=300):
     """HBM traffic measured IN THIS RUN: two rocprofv3 passes (one PMC counter each, FETCH_SIZE then WRITE_SIZE, with --kernel-trace
     only -- the collection MI355X_MICROARCH.md prescribes) of a 3-forward child run of this very script, read from rocprofv3's
@@ -246,26 +261,45 @@ def live_pmc_traffic(a, timeout_s=300):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
             # the program itself follows `--` (no env / shell / launcher hop: the profiler's preloaded library has initialised the GPU)
-            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", os.path.realpath(sys.executable)] + child, cwd="/tmp", env=env,
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "p", "--", profiled_interpreter()] + child, cwd="/tmp", env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
                 raise RuntimeError(f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stdout or '')[-400:]}")
             rows = sqlite3.connect(dbs[0]).execute(
-                "select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? group by kernel_name, dispatch_id",
-                (ctr,)).fetchall()
+                "select kernel_name, grid_size, dispatch_id, sum(value) from counters_collection where counter_name = ? "
+                "group by kernel_name, grid_size, dispatch_id", (ctr,)).fetchall()
             if not rows:
                 raise RuntimeError(f"no {ctr} samples in {dbs[0]}")
-            key = launch_sites(a.points)[0]["trace_key"]
-            prof = [v for k, _, v in rows if key in k]
-            if key == PROFILED_KERNEL_KEY:      # that kernel runs at three launch sites per forward (enc.sa2.1, both hands): all sampled
-                prof = [v for k, _, v in rows if key in k and "sa_mlp_max" in k]
-            sums[ctr] = (sum(v for _, _, v in rows), sum(prof) / max(len(prof), 1), len(prof))
+            per_site = {}
+            for site in launch_sites(a.points):
+                vals = site_dispatch_values(site["tag"], rows)
+                if not vals:            # never publish a "measured 0 bytes": a site that matches no dispatch is an error
+                    raise RuntimeError(f"no dispatch of launch site {site['tag']} found in the {ctr} pass")
+                per_site[site["tag"]] = (sum(vals) / len(vals), len(vals))
+            sums[ctr] = (sum(r[3] for r in rows), per_site)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"kernel": int((2 * sums["FETCH_SIZE"][1] + sums["WRITE_SIZE"][1]) * 1024),
+    tag1 = launch_sites(a.points)[0]["tag"]
+    sites = {t: {"bytes": int((2 * sums["FETCH_SIZE"][1][t][0] + sums["WRITE_SIZE"][1][t][0]) * 1024), "launches_sampled": sums["FETCH_SIZE"][1][t][1]}
+             for t in sums["FETCH_SIZE"][1]}
+    return {"kernel": sites[tag1]["bytes"], "sites": sites,
             "step": int((2 * sums["FETCH_SIZE"][0] + sums["WRITE_SIZE"][0]) * 1024 / nsteps),
-            "kernel_launches_sampled": sums["FETCH_SIZE"][2]}
+            "kernel_launches_sampled": sites[tag1]["launches_sampled"]}
+
+
+def site_dispatch_values(tag, rows):
+    """The counter values of the dispatches that belong to one launch site, from (kernel_name, grid_size, dispatch_id, value) rows.
+    Independent of trailing template arguments and of the arithmetic mode: `sa2.1` = the fused set-abstraction kernel with the
+    widths 128-196-256 (three launch sites per forward run it at the same shape: all are sampled); `qconv0` = the k = 3 query
+    convolution = the dense-layer (gemm_nt*) launch with the LARGEST grid of the forward in every mode."""
+    if tag == PROFILED_TAG:
+        return [v for k, _, _, v in rows if PROFILED_KERNEL_KEY in k and "sa_mlp_max" in k]
+    gemm = [(g, v) for k, g, _, v in rows if "gemm_nt" in k]
+    if not gemm:
+        return []
+    gmax = max(g for g, _ in gemm)
+    return [v for g, v in gemm if g == gmax]
 
 
 def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None, site=None):
@@ -705,7 +739,8 @@ def run_rank(a) -> int:
             res["roofline"] = roofline_entry(a.precision, B, main_kernel_ms, live["kernel"] if live_is_site1 else None,
                                              live_src if live_is_site1 else None, site=site1)
             if second_kernel_ms:
-                res["roofline_second"] = roofline_entry(a.precision, B, second_kernel_ms, site=site2)
+                t2 = live["sites"][site2["tag"]]["bytes"] if live and "sites" in live and site2["tag"] in live["sites"] else None
+                res["roofline_second"] = roofline_entry(a.precision, B, second_kernel_ms, t2, live_src if t2 is not None else None, site=site2)
             res["hbm"] = hbm_entry(B, N, dt / a.steps * 1e3, live.get("step") if live else None, live_src)
             f32_leg = legs.pop("f32", None)
             if f32_leg:

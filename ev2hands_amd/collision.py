@@ -31,10 +31,12 @@ def device_faces(faces, dev) -> torch.Tensor:
 
 
 def mesh_collisions(verts_left: torch.Tensor, verts_right: torch.Tensor, faces_left, faces_right, max_pairs: int = 0,
-                    scale: float = 1000.0, max_per_triangle: int = 0):
+                    scale: float = 1000.0, max_per_triangle: int = 0, scratch: torch.Tensor | None = None):
     """verts_* [B,nv,3] float32 metres on the GPU, faces_* [nf,3] (ndarray or tensor).  Returns (counts [B] int32 tensor,
     pairs [B,max_pairs,2] int32 tensor or None; rows past counts[b] are unspecified).  max_per_triangle: the BVH's
-    `max_collisions` cap (0 = none), see ev2h_mesh_collisions."""
+    `max_collisions` cap (0 = none), see ev2h_mesh_collisions.  scratch: optional caller-owned uint8 buffer of at least
+    `ev2h_mesh_collisions_scratch_bytes(B, nf)` bytes, used on the CURRENT stream only (the phases of one search communicate
+    through it); without one a buffer cached per (device, stream) is used."""
     B, nv, _ = verts_left.shape
     dev = verts_left.device
     vl = verts_left.to(torch.float32).contiguous()
@@ -45,7 +47,11 @@ def mesh_collisions(verts_left: torch.Tensor, verts_right: torch.Tensor, faces_l
     pairs = torch.empty(B, max_pairs, 2, device=dev, dtype=torch.int32) if max_pairs > 0 else None
     L = _lib.lib()
     # a scratch buffer lets the library split a window's row blocks over two workgroups when the batch alone cannot fill the chip
-    scratch = _scratch(L.ev2h_mesh_collisions_scratch_bytes(B, nf), dev) if B <= 128 else None
+    if scratch is None and B <= 128:
+        scratch = _scratch(L.ev2h_mesh_collisions_scratch_bytes(B, nf), dev)
+    elif scratch is not None:
+        if scratch.device != vl.device or scratch.dtype != torch.uint8 or not scratch.is_contiguous():
+            raise ValueError("mesh_collisions: scratch must be a contiguous uint8 tensor on the vertices' device")
     _lib.check(L.ev2h_mesh_collisions_ws(vl.data_ptr(), vr.data_ptr(), fl.data_ptr(), fr.data_ptr(), B, nv, nf, float(scale),
                                          max_pairs, _lib.ptr(pairs), counts.data_ptr(), int(max_per_triangle), _lib.ptr(scratch),
                                          scratch.numel() if scratch is not None else 0, _lib.stream_handle()),
@@ -56,11 +62,20 @@ def mesh_collisions(verts_left: torch.Tensor, verts_right: torch.Tensor, faces_l
 _SCRATCH = {}
 
 
-def _scratch(nbytes: int, dev) -> torch.Tensor:
-    """per-device scratch for ev2h_mesh_collisions_ws, grown on demand (calls on one stream are ordered, so it is shared)"""
-    t = _SCRATCH.get(str(dev))
-    if t is None or t.numel() < nbytes:
-        t = _SCRATCH[str(dev)] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+def _scratch(nbytes: int, dev):
+    """Scratch for ev2h_mesh_collisions_ws, one buffer per (device, STREAM), grown on demand.  The three phases of a search
+    communicate through it, so two searches may share it only when they are ordered -- i.e. on one stream; searches on different
+    streams (a user's own, or the library's main / side schedule) get different buffers.  A buffer that is outgrown goes back to
+    the caching allocator on the stream that used it, which is the allocator's own ordering rule.  During a stream capture nothing
+    may be allocated: a search that finds no (large enough) buffer then runs without one (one workgroup per window)."""
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream()
+        key = (str(dev), int(st.cuda_stream))
+        t = _SCRATCH.get(key)
+        if t is None or t.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            t = _SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return t
 
 

@@ -965,12 +965,22 @@ int ev2h_gemm_tile_geometry(int ns, int out[2]) {
 }
 
 // The first query convolution with the attention's key-weighted sums as its output (zsum_epilogue): d describes the k = 3 GEMM as for
-// ev2h_gemm (d->Y unused), key_pm = logits point-major [M][4], zpart [M / 128][12][N].  Internal (forward.hip); returns
-// EV2H_ERR_ARG for shapes the tap kernel does not take -- the caller then runs the two-pass form.
+// ev2h_gemm (d->Y unused), key_pm = logits point-major [M][4], zpart [M / 128][12][N].  Internal (forward.hip).
+// ev2h_gemm_bf16_zsum_supported: the shapes the tap kernel takes -- the caller tests them FIRST and runs the two-pass form otherwise;
+// an error of the launch itself is then an error, not a silent change of schedule.
+bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d) {
+    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_BF16) &&
+          d->K % GB_BK == 0 && d->rows_per_seq > 0 && d->rows_per_seq % GB_BM == 0 && d->M % d->rows_per_seq == 0 && d->N % GO_BN == 0))
+        return false;
+    if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+        const int xg = d->x_group_rows > 0 ? d->x_group_rows : 1;
+        if (xg % GB_BM != 0 || xg % d->rows_per_seq != 0) return false;
+    }
+    return true;
+}
+
 int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, ev2h_stream_t stream) {
-    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && d->precision != EV2H_PREC_F32 && d->K % GB_BK == 0 && d->rows_per_seq % GB_BM == 0 &&
-          d->M % d->rows_per_seq == 0 && d->N % GO_BN == 0 && key_pm && zpart))
-        return EV2H_ERR_ARG;
+    EV2H_CHECK_ARG(d && key_pm && zpart && ev2h_gemm_bf16_zsum_supported(d));
     GemmBP p{};
     p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = nullptr; p.ldy = 0;
     p.M = d->M; p.N = d->N; p.taps = 3; p.Kc = d->K; p.K = d->K * 3;
@@ -980,7 +990,6 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     p.x_group_rows = p.y_group_rows = 1;
     if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
         p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
-        if (p.x_group_rows % GB_BM != 0 || p.x_group_rows % d->rows_per_seq != 0) return EV2H_ERR_ARG;
     }
     p.zs_key = reinterpret_cast<const float4*>(key_pm); p.zs_out = zpart;
     p.tiles_n = d->N / GO_BN;

@@ -171,6 +171,7 @@ struct BallArgs {
     int32_t* gidx[3];
     int32_t* cnt;   // [B][S][nrad] (may be null)
     int cpw;        // centroids per workgroup (multiple of 4: one per wave and round)
+    int nchunk;     // workgroups per window = ceil(S / cpw); the grid is 1-D: nchunk * B workgroups
 };
 
 constexpr int BALL_CTR_PER_WG = 32, BALL_UNR = 4;
@@ -181,7 +182,12 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
                                                          int N, int S, BallArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* spts = reinterpret_cast<float4*>(smem_raw);
-    const int b = blockIdx.y;
+    // XCD-aware 1-D grid: the dispatcher deals workgroups to the 8 XCDs round-robin; xcd_remap gives every XCD a CONTIGUOUS range
+    // of (window, chunk) pairs, so that the workgroups that scan one window's points sit on one XCD and find them in its L2.
+    // (A [chunk, window] 2-D grid spread every window over all 8 L2s: at 128 windows of 8192 points each L2 saw all 16.8 MB of
+    // points and the launch fetched 2.5 GB -- 150 x its input -- profiles/r4_pmc_hbm_traffic_n8192_f16x2.json.)
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = L / a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* src = pts4 + (size_t)b * N;
     if constexpr (LDS_PTS) {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
         __syncthreads();
     }
 
-    const int s_begin = blockIdx.x * a.cpw;
+    const int s_begin = (L - b * a.nchunk) * a.cpw;
     for (int s = s_begin + wave; s < s_begin + a.cpw && s < S; s += 4) {
         const float4 c = ctr4[(size_t)b * S + s];
         int cnt[3] = {0, 0, 0};
@@ -421,12 +427,18 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     // time: 16 workgroups for enc.sa1 at B = 1) takes fewer per workgroup instead -- same per-centroid arithmetic, same results
     a.cpw = BALL_CTR_PER_WG;
     while (a.cpw > 4 && (long)ceil_div(S, a.cpw) * B < 256) a.cpw >>= 1;
-    dim3 grid(ceil_div(S, a.cpw), B);
+    // the L2 form (below) stages nothing, so a workgroup costs nothing to start: one centroid per wave -- a scan is a chain of
+    // dependent L2 round trips with a data-dependent early exit, and many short waves hide both the latency and the imbalance
+    // (16 windows of 8192 points, enc.sa1: 266 -> see DESIGN.md section 11; 32 centroids per workgroup left 8 scans in a row per wave)
+    static const int lds_max = getenv("EV2H_BALL_LDS_MAX") ? atoi(getenv("EV2H_BALL_LDS_MAX")) : 2048;
+    const bool l2_form = N > 8192 || N > lds_max;
+    if (l2_form) a.cpw = 4;
+    a.nchunk = ceil_div(S, a.cpw);
+    dim3 grid((unsigned)a.nchunk * (unsigned)B);
     // Windows above EV2H_BALL_LDS_MAX points (default 2048: the reference's operating point keeps the LDS form, measured neutral there) read their points from L2 instead of staging them in LDS: at N = 8192 the
     // 128 KB of staged points leave ONE 4-wave workgroup per CU, and the scan is latency-bound -- the L2 form is 3x faster there
     // (1.74 -> ~0.5 ms per 128 windows; BASELINE config 5's shape +14.6 % windows/s, same-box A/B).  Same arithmetic, same results.
-    static const int lds_max = getenv("EV2H_BALL_LDS_MAX") ? atoi(getenv("EV2H_BALL_LDS_MAX")) : 2048;
-    if (N > 8192 || N > lds_max) {
+    if (l2_form) {
         ball_query_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;

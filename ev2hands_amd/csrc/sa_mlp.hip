@@ -266,6 +266,12 @@ extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d->B > 0 && d->S > 0 && d->Npts > 0 && d->K >= 32 && (d->K % 32) == 0);
     EV2H_CHECK_ARG((d->ldp % 4) == 0);
     if (d->precision != EV2H_PREC_F32) return ev2h_sa_mlp_max_bf16(d, stream);
+    // exact fp32: layer 1 is the gathered table row + the relative-coordinate term; the raw-feature form (ev2h_sa_desc.feat
+    // without a table) exists on the matrix pipe only
+    if (!d->P1) {
+        ev2h_set_error("ev2h_sa_mlp_max: EV2H_PREC_F32 needs the layer-1 table P1 (feature rows without a table: BF16 / F16X2 only)");
+        return EV2H_ERR_ARG;
+    }
     EV2H_CHECK_ARG(d->W2 && d->W3);
     SaP p{};
     p.P1 = d->P1; p.ldp = d->ldp; p.pts4 = (const float4*)d->pts4; p.ctr4 = (const float4*)d->ctr4; p.gidx = d->gidx;

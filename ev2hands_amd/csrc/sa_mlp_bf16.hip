@@ -93,7 +93,11 @@ struct SaBCfg {
     // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
     // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
     static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 16;
-    static constexpr int SMALL = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
+    // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, one 64-bit (window, max) key in the
+    // resident one -- see the kernel's epilogue
+    static constexpr int REC = (NS == 2) ? 64 : 0;
+    static constexpr int SMALL_NOREC = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
+    static constexpr int SMALL = SMALL_NOREC + REC;
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
     static constexpr bool fits(int n) { return NC1 % n == 0 && T3 % n == 0 && 2 * tile_bytes(n, n) + SMALL <= 158 * 1024; }
     static constexpr int CPT = fits(2) ? 2 : 1, UPT = CPT;
@@ -256,6 +260,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     auto dma_w3 = [&](int step, char* dst) { dma_tile(p.W3s + (size_t)step * UPT * Cfg::TB3, dst, UPT * Cfg::TB3); };
 
     int buf = 0;
+    if constexpr (RES && NS == 2) {
+        if (tid == 0) *reinterpret_cast<unsigned long long*>(smem + WBYTES + Cfg::SMALL_NOREC) = 0ull;      // (window, max) key of the record combine
+    }
     if constexpr (RES) {
         dma_tile(p.W2s, smem, NC1 * Cfg::TB2);
         dma_tile(p.W3s, smem + NC1 * Cfg::TB2, T3 * Cfg::TB3);
@@ -930,9 +937,40 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         }
     }
     if constexpr (NS == 2) {
+        // Range record of the output (ev2hands_hip.h "Range records"): amax[b] = max over the window's groups.  One device-scope
+        // atomicMax per GROUP put 512 read-modify-writes on one address per window and launch; across the 8 XCDs these are
+        // executed one after the other at the memory side, and a launch of a few windows (16 windows of 8192 points = one rank's
+        // share of BASELINE config 5) spent more time draining them than computing (enc.sa1: 14 -> 99, 44 -> 109 us at 16
+        // windows, tools/debug/sa_small_grid.py).  The waves of a workgroup work on consecutive groups -- almost always one
+        // window -- so their maxima are combined in LDS first:
+        //  * streamed variants (the waves already meet at barriers): one atomic per (workgroup, window);
+        //  * resident variant (barrier-free persistent waves): a 64-bit LDS key (window, max) filters the updates -- a wave only
+        //    goes to memory when it raises its workgroup's running maximum of the window (windows ascend along a wave's walk).
+        // max is exact, associative and idempotent: the record is the same number whatever the route.
         if (p.out_amax) {
             am = wave_max_u32_dpp(am);
-            if (lane == 0 && am) atomicMax(&p.out_amax[b], am);
+            char* rec = smem + WBYTES + Cfg::SMALL_NOREC;
+            if constexpr (RES) {
+                if (lane == 0 && am) {
+                    const unsigned long long key = ((unsigned long long)(unsigned)b << 32) | am;
+                    const unsigned long long old = atomicMax(reinterpret_cast<unsigned long long*>(rec), key);
+                    if (key > old) atomicMax(&p.out_amax[b], am);
+                }
+            } else {
+                int* sb = reinterpret_cast<int*>(rec);
+                unsigned* sa = reinterpret_cast<unsigned*>(rec + 32);
+                if (lane == 0) { sb[wave] = (valid && am) ? b : -1; sa[wave] = am; }
+                __syncthreads();
+                if (lane == 0 && valid && am) {
+                    bool first = true;
+                    unsigned m = am;
+#pragma unroll
+                    for (int w = 0; w < WV; ++w) {
+                        if (sb[w] == b) { first = first && w >= wave; m = max(m, sa[w]); }
+                    }
+                    if (first) atomicMax(&p.out_amax[b], m);
+                }
+            }
         }
     }
     if constexpr (!RES) break;

@@ -66,11 +66,13 @@ def stats(t: torch.Tensor) -> np.ndarray:
     return np.array([t.mean().item(), t.abs().max().item(), t.pow(2).mean().sqrt().item()])
 
 
-def run_case(pn, te, name, kind, C, N, B, seed):
+def run_case(pn, te, name, kind, C, N, B, seed, sd_override=None, extra=None):
+    """`sd_override`: a checkpoint other than synth_state_dict(C, seed) (oracle/make_golden_trained.py: weights that came out of
+    the reference's own training loop); `extra`: additional arrays to store with the fixture."""
     os.environ["ERPC"] = "1" if C == 5 else "0"
     mhlnes = name.endswith("_mhlnes")
     os.environ["MHLNES"] = "1" if mhlnes else "0"
-    sd = synth.synth_state_dict(C, seed)
+    sd = synth.synth_state_dict(C, seed) if sd_override is None else sd_override
     net = te.TEHNet(n_pose_params=synth.MANO_CMPS)
     assert net.mhlnes == int(mhlnes)
     net.load_state_dict(sd, strict=True)
@@ -194,6 +196,8 @@ def run_case(pn, te, name, kind, C, N, B, seed):
         out["tie_eps"] = np.array(TIE_EPS)
         print(f"{name}: logit scale {scale:.3g}; top-2 margin < 1e-5 scale at {float((m < 1e-5 * scale).float().mean()) * 100:.2f} % of the points, "
               f"< 1e-6 scale at {float((m < 1e-6 * scale).float().mean()) * 100:.2f} %, exact ties {int((m == 0).sum())}")
+    if extra:
+        out.update(extra)
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")

@@ -276,3 +276,52 @@ def test_gpu_two_workgroups_per_window_equal_one(mesh):
             assert torch.equal(p1[b, :n], p2[b, :n]), (max_pairs, cap, b)
     print(f"{mesh}: pairs per window {c1.tolist()}")
     assert int(c1.max()) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_searches_on_two_streams_do_not_share_scratch():
+    """mesh_collisions' cached scratch is per (device, stream): two searches in flight on different streams used to share one
+    buffer (row counters of one search overwritten by the other's phases -- ADVICE r4).  Many interleaved searches on two streams
+    must reproduce the single-stream lists, and a caller-owned scratch buffer is accepted."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ev2hands_amd import collision as col, synth
+    from ev2hands_amd.mano import ManoHand
+    B = 5
+    hands = {s: ManoHand(synth.synth_mano_surface_assets(s, 2), "cuda") for s in ("left", "right")}
+    g = lambda n, sc, sd: torch.from_numpy(synth.hash_normal("c" + str(n), (B, n), sd) * sc).float().cuda()      # noqa: E731
+    sets = []
+    for sd in (7, 8):
+        out = {s: hands[s](g(3, 0.4, sd), g(6, 0.6, sd), g(10, 0.5, sd), g(3, 0.01, sd)) for s in hands}
+        sets.append((out["left"].vertices.contiguous(), (out["right"].vertices + torch.tensor([0.03, 0.0, 0.0], device="cuda")).contiguous()))
+    fl, fr = hands["left"].faces, hands["right"].faces
+    cap, mp = 16, 2 * 1538 * 16
+    ref = [col.mesh_collisions(vl, vr, fl, fr, max_pairs=mp, scale=1.0, max_per_triangle=cap) for vl, vr in sets]
+    torch.cuda.synchronize()
+    ref = [(c.cpu(), p.cpu()) for c, p in ref]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    got = [[], []]
+    for _ in range(6):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                got[i].append(col.mesh_collisions(*sets[i], fl, fr, max_pairs=mp, scale=1.0, max_per_triangle=cap))
+    torch.cuda.synchronize()
+    assert len({k for k in col._SCRATCH if k[0].startswith("cuda")}) >= 3          # default stream + the two side streams
+    for i in range(2):
+        for c, p in got[i]:
+            assert torch.equal(c.cpu(), ref[i][0])
+            for b in range(B):
+                n = int(ref[i][0][b])
+                assert torch.equal(p[b, :n].cpu(), ref[i][1][b, :n])
+    own = torch.empty(_scratch_bytes(B), dtype=torch.uint8, device="cuda")
+    c, p = col.mesh_collisions(*sets[0], fl, fr, max_pairs=mp, scale=1.0, max_per_triangle=cap, scratch=own)
+    assert torch.equal(c.cpu(), ref[0][0])
+    with pytest.raises(ValueError):
+        col.mesh_collisions(*sets[0], fl, fr, scratch=torch.empty(16, dtype=torch.float32, device="cuda"))
+
+
+def _scratch_bytes(B, nf=1538):
+    from ev2hands_amd import _lib
+    return _lib.lib().ev2h_mesh_collisions_scratch_bytes(B, nf)

@@ -77,3 +77,18 @@ def test_bench_live_hbm_traffic_counts_the_forwards_only():
     assert 10e6 < per_window < 90e6, per_window
     t = j["roofline"]["traffic"]
     assert t is None or 1e6 < t < 400e6, t
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "bf16"])
+def test_bench_live_traffic_at_n8192_names_the_query_convolution(precision):
+    """BASELINE config 5's window size: the dominant launch is the k = 3 query convolution, whose traced kernel name depends on
+    the arithmetic mode and on template arguments added over the rounds -- bench.py once matched none of its dispatches and
+    published a `measured` 0 bytes.  Both launch sites must now carry their own PMC traffic (or the source must say why not)."""
+    j = _run("--points", "8192", "--batch", "4", "--precision", precision, "--no-host-io", traffic=True)
+    assert j["roofline"]["launch_site"] == "qconv0" and j["roofline_second"]["launch_site"] == "sa2.1"
+    if "measured in this run" not in str(j["hbm"].get("source", "")):
+        pytest.skip(f"live PMC passes unavailable on this box: {j['hbm'].get('source')}")
+    # the GEMM reads 4 windows x 8192 rows x 256 fp32 (33.5 MB) at least once and writes nothing but partial sums
+    t1, t2 = j["roofline"]["traffic"], j["roofline_second"]["traffic"]
+    assert t1 is not None and 20e6 < t1 < 400e6, t1
+    assert t2 is not None and 1e6 < t2 < 400e6, t2

@@ -371,3 +371,19 @@ def test_surface_like_synthetic_hand_assets():
     for i in range(2):
         vv, ff = CO.build_triangles(v["left"][i], v["right"][i], a["left"]["faces"], a["right"]["faces"], scale=1000.0)
         assert CO.collision_pairs(vv, ff, 8).shape[0] < 1000
+
+
+def test_bench_launch_site_matching_is_independent_of_template_arguments():
+    """bench.py picks the dispatches of its two launch sites out of a rocprofv3 counter table: the set-abstraction kernel by its
+    widths, the k = 3 query convolution as the dense-layer launch with the largest grid -- in every arithmetic mode, whatever
+    trailing template arguments the kernels have grown (a hard-coded `<2, true>` matched nothing at N = 8192)."""
+    import bench
+    for gemm in ("gemm_nt_bf16_occ_kernel<2, true, false>", "gemm_nt_bf16_occ_kernel<1, true, false, 7>", "gemm_nt_kernel"):
+        rows = [("void (anonymous namespace)::sa_mlp_max_bf16_kernel<128, 196, 256, 2, false, 0>(SaArgs)", 1048576, 1, 5.0),
+                ("void (anonymous namespace)::sa_mlp_max_bf16_kernel<128, 128, 256, 2, false, 0>(SaArgs)", 1048576, 2, 3.0),
+                (gemm, 8388608, 3, 7.0), (gemm.replace("true", "false"), 262144, 4, 1.0), (gemm, 8388608, 5, 9.0)]
+        assert bench.site_dispatch_values("sa2.1", rows) == [5.0]
+        assert bench.site_dispatch_values("qconv0", rows) == [7.0, 9.0]
+    assert bench.site_dispatch_values("qconv0", [("fps_kernel<8>", 256, 1, 1.0)]) == []
+    assert {s["tag"] for s in bench.launch_sites(8192)} == {"sa2.1", "qconv0"} and bench.launch_sites(8192)[0]["tag"] == "qconv0"
+    assert bench.launch_sites(2048)[0]["tag"] == "sa2.1"

@@ -11,7 +11,7 @@ import torch
 from ev2hands_amd import synth
 from oracle import mano_oracle, tehnet_oracle
 
-CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_")))
+CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_weights")))
 
 
 def rel(a, b):
@@ -29,7 +29,12 @@ def test_oracle_matches_reference_fixture(path):
     assert np.array_equal(xyz.numpy(), g["xyz"]), "synthetic input generator drifted"
     inits = synth.fps_inits(B, N, seed)
     assert np.array_equal(torch.stack(inits).numpy(), g["fps_init"])
-    sd = synth.synth_state_dict(C, seed)
+    if "ckpt" in g.files:          # weights that came out of the reference's training loop (oracle/make_golden_trained.py)
+        import trained_ckpt
+        assert str(g["ckpt"]) == "trained"
+        sd = trained_ckpt.trained_state_dict(C)
+    else:
+        sd = synth.synth_state_dict(C, seed)
     hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
     if "tie_eps" in g.files:       # near-tie segmentation head (oracle/stress.py)
         from oracle import stress

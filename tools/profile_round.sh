@@ -10,7 +10,7 @@ TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-PY=$(python3 -c "import os,sys; print(os.path.realpath(sys.executable))")   # the real ELF interpreter follows `--` (no shim / shell hop under the profiler)
+PY=$(python3 -c "import sys; print(sys.executable)")   # the interpreter itself follows `--`; a symlink is not an exec hop and resolving it would leave a virtualenv
 BENCH="bench.py --steps 7 --warmup 3 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
 SMALL="bench.py --steps 2 --warmup 1 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
 for prec in f16x2 f32 bf16x3 bf16; do
