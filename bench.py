@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=256, help="event windows per GPU per step")
     ap.add_argument("--points", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="forwards in flight (ev2hands_amd/inflight.py: step i on stream i mod K with its own workspace); for shards too small to fill "
+                         "the chip, e.g. --points 8192 --batch 16 --inflight 2.  Default 1: one forward at a time on one stream")
     ap.add_argument("--cloud", default="E", choices=["U", "E"])
     ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f16x2"), choices=["f32", "bf16x3", "f16x2", "bf16"],
                     help="arithmetic of the MFMA contractions: f16x2 = fp32-class 2-plane fp16 split with per-window range scaling "
@@ -441,6 +444,7 @@ def run_rank(a) -> int:
     g_inits = synth.fps_inits(gB, N, 7)                    # drawn for the GLOBAL batch, then sliced (sharded == unsharded)
     inits = evdist.shard_fps_inits(g_inits, lo, hi)
 
+    infl = None
     if a.stub:
         net = L = ev = sd = assets = None
 
@@ -469,21 +473,29 @@ def run_rank(a) -> int:
             closs = evcol.CollisionLoss(dev)
             dev_faces = (evcol.device_faces(net.hands["left"].faces, dev), evcol.device_faces(net.hands["right"].faces, dev))   # converted ONCE
 
+        if a.inflight > 1:
+            from ev2hands_amd.inflight import InflightForward
+            infl = InflightForward(net, a.inflight)
+
+        def collision_terms(out):
+            if closs is not None:
+                # device-side only: the face tables were uploaded in the set-up (a pageable host->device copy per call would
+                # synchronise the stream six times per step).  BASELINE config 5 names the intersection-LOSS term (losses.py:60-102:
+                # pair search with max_collisions = 16 + conic distance-field penalty); --collision-score adds the evaluation
+                # script's count (evaluate_ev2hands_r.py:128-160: a second search with max_collisions = 8), which the reference
+                # never runs in the same step
+                if a.collision_score:
+                    out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], dev_faces[0], dev_faces[1],
+                                                                      max_per_triangle=8)
+                out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
+            return out
+
         def forward(rows=None):
             net.net.fps_init = inits
+            if infl is not None:                       # K forwards in flight: returns a ticket, the work is on stream i mod K
+                return infl.submit(xyz, rows=rows, post=collision_terms)
             with torch.no_grad():
-                out = net.net(xyz, net.hands, rows=rows)
-                if closs is not None:
-                    # device-side only: the face tables were uploaded in the set-up (a pageable host->device copy per call would
-                    # synchronise the stream six times per step).  BASELINE config 5 names the intersection-LOSS term (losses.py:60-102:
-                    # pair search with max_collisions = 16 + conic distance-field penalty); --collision-score adds the evaluation
-                    # script's count (evaluate_ev2hands_r.py:128-160: a second search with max_collisions = 8), which the reference
-                    # never runs in the same step
-                    if a.collision_score:
-                        out["collision_count"], _ = evcol.mesh_collisions(out["left"]["vertices"], out["right"]["vertices"], dev_faces[0], dev_faces[1],
-                                                                          max_per_triangle=8)
-                    out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
-                return out
+                return collision_terms(net.net(xyz, net.hands, rows=rows))
 
     # multi-GPU: the forward writes its windows straight into this rank's slice of a persistent gather buffer (ev2h_outputs'
     # window strides), then ONE in-place all-gather -- no packing copy, no allocation per step.  Two buffers alternate and the
@@ -499,11 +511,15 @@ def run_rank(a) -> int:
         if a.stub:
             rows.copy_(evdist.pack_outputs(forward()))
         else:
-            forward(rows)
+            t = forward(rows)
+        if infl is not None:
+            t.result()                                 # the gather is issued on the caller's stream: it waits for that forward
         pending = pipe.submit()
         return pending.result() if sync_gather else pending
 
     def sync():
+        if not a.stub and infl is not None:
+            infl.drain()
         if pipe is not None:
             pipe.drain()
         if use_dist:
@@ -706,7 +722,7 @@ def run_rank(a) -> int:
                                       ("mitten-shaped surfaces with smooth skinning (tens to hundreds of colliding pairs per window)" if a.collision_mesh == "surface"
                                        else "random triangle soup (every mesh intersects itself ~24 000 times: worst case for the pair search)")
                                       if a.collision else ""),
-                       "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision,
+                       "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision, "forwards_in_flight": a.inflight,
                        "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
                        "parallelism": f"batch-shard x{world}" + ((" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer; " +
                                                                        ("in stream order)" if sync_gather else "asynchronous, overlapped with the next forward)")) if use_dist else "")},

@@ -376,10 +376,8 @@ extern "C" int ev2h_mesh_collisions_ws(const float* verts_left, const float* ver
                                            160 * 1024)););
     // One 1024-thread workgroup (142 KB of LDS) per window fills one CU: below 256 windows CUs idle (BASELINE config 5 runs B = 128 per
     // GPU).  With a scratch buffer a window's row blocks are split over two workgroups (more cannot help: row block 0 alone scans all
-    // 49 column blocks).  EV2H_COLLISION_SPLIT=1 forces one workgroup (A/B).
-    static const int forced = getenv("EV2H_COLLISION_SPLIT") ? atoi(getenv("EV2H_COLLISION_SPLIT")) : 0;
-    int nsplit = (scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf) && B <= 128) ? 2 : 1;
-    if (forced == 1 || (forced == 2 && scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf))) nsplit = forced;
+    // 49 column blocks).  The caller chooses: no scratch buffer = one workgroup per window.
+    const int nsplit = (scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf) && B <= 128) ? 2 : 1;
     if (nsplit == 1) {
         mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
         EV2H_CHECK_LAUNCH();

@@ -190,13 +190,6 @@ static const char* const kRangeNames[R_COUNT] = {
     "feat", "l1a", "l1b", "l2", "sa3h1", "sa3h2", "l3", "fp3h", "fp3o", "fp2h", "l1new", "fp1in", "fp1h1", "fp1h2", "l0", "clsh", "q1",
     "hfL", "hfR", "m1L", "m1R", "msa2hL", "msa2hR", "m2L", "m2R", "fc1L", "fc1R", "p1a", "p1b", "p1mL", "p1mR", "fp1t"};
 
-// A/B switch (EV2H_ATTN_UNFOLDED=1): the second query convolution as two k=3 GEMMs + ev2h_attn_sim; only then does the workspace
-// hold their output (4.2 MB per window)
-static bool attn_unfolded() {
-    static const bool on = getenv("EV2H_ATTN_UNFOLDED") != nullptr;
-    return on;
-}
-
 static void build_layout(Layout& L, int B, int N) {
     const size_t R = (size_t)B * N;
     const size_t b = (size_t)B;
@@ -233,7 +226,6 @@ static void build_layout(Layout& L, int B, int N) {
     L.add("clsh", R * 256);
     L.add("logits_pm", R * 4);
     L.add("q1", R * 512);
-    if (attn_unfolded()) L.add("q2", 2 * R * 256);
     L.add("zpart", std::max(ev2h_attn_sim_folded_scratch(B, N), (size_t)B * ceil_div(N, 128) * 12 * 512));     // (fused form: one partial per 128 rows)
     L.add("sim", b * 2 * 4 * 256);
     L.add("hf8", 2 * R * 8);
@@ -328,9 +320,9 @@ static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, i
 
 // BF16 with raw feature rows (kf == 8: enc.sa1, the regressors' sa1): layer 1 runs on the matrix pipe inside the fused kernel straight
 // from the feature rows (ev2h_sa_desc.feat) -- no layer-1 table is computed, written (1.46 GB per 256-window step) or gathered.
-// EV2H_BF16_TABLE=1: A/B switch back to the table.
+// EV2H_L1_TABLE=1: A/B switch back to the table (the path BF16X3 and F32 always take).
 static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
-    static const bool table = getenv("EV2H_BF16_TABLE") != nullptr || getenv("EV2H_L1_TABLE") != nullptr;
+    static const bool table = getenv("EV2H_L1_TABLE") != nullptr;
     return (precision == EV2H_PREC_BF16 || precision == EV2H_PREC_F16X2) && m.kf == 8 && !table;
 }
 
@@ -360,8 +352,7 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
             d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
         }
-        static const bool no_skip = getenv("EV2H_SA_NO_SKIP") != nullptr;       // A/B switch: process padding strips too
-        d.cnt = (cnt && !no_skip) ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
+        d.cnt = cnt ? cnt + i : nullptr; d.cnt_ld = m.nbranch;      // padding-only strips are skipped (bit-identical: test_sa_mlp_max_padding_skip)
         char t[40];
         snprintf(t, sizeof(t), "%s.%d", tag, i);
         prof_begin(t, st);
@@ -526,11 +517,11 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     // fork 0: the layer-1 table of enc.sa1 needs the prepared input only; it is written (HBM-bound) on the side stream while the
     // farthest-point sampling (latency-bound, 896 dependent steps) and the ball query run on the caller's stream
     const bool fork = side != nullptr;
-    static const bool extra = !(getenv("EV2H_EXTRA_OVERLAP") && atoi(getenv("EV2H_EXTRA_OVERLAP")) == 0);   // A/B: table + classifier on the side stream
+    // sd: the side stream (or the caller's in single-stream mode, EV2H_TWO_STREAMS=0 / ev2h_set_side_stream(0)).  On it: the
+    // layer-1 table, every selection that needs only coordinates, the classifier, and the right hand's regressor.
     ev2h_stream_t sd = fork ? (ev2h_stream_t)side->stream : st;
-    ev2h_stream_t sx = (fork && extra) ? sd : st;
-    static const bool coord = !(getenv("EV2H_COORD_OVERLAP") && atoi(getenv("EV2H_COORD_OVERLAP")) == 0);   // A/B: coordinate-only selections on the side stream
-    ev2h_stream_t sc = coord ? sx : st;
+    ev2h_stream_t sx = sd;
+    ev2h_stream_t sc = sd;
     if (fork) {
         EV2H_CHECK_HIP(hipEventRecord(side->ev[4], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[4], 0));
@@ -591,7 +582,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {
         const ev2h_sa_module& m = w->sa2;
-        if (fork && extra && coord) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[8], 0));
+        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[8], 0));
         RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi2, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
                       ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2)));
         write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
@@ -618,7 +609,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
         // the two hidden layers (3 x 268 MB written and read back at B = 256) never reach memory
         const ev2h_sa_module& m = w->fp1m;
-        if (fork && extra && coord) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[9], 0));      // 3-NN selection: fork 1 above
+        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[9], 0));      // 3-NN selection: fork 1 above
         RUN(sa_table(prec, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
         ev2h_fp_desc d{};
         d.T = ws.f("fp1T"); d.ldt = 128; d.nn_idx = ws.i("nn1_idx"); d.nn_w = ws.f("nn1_w");
@@ -667,10 +658,9 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     // [r4] BF16 / F16X2: q1 is NOT WRITTEN -- the GEMM's epilogue forms the attention's key-weighted sums of its own tile
     // (gemm_bf16.hip: zsum_epilogue), which makes the logits its input: the classifier is waited for first.
     // EV2H_ATTN_UNFUSED_ZSUM=1: A/B switch (q1 to memory, attn_zsum_kernel reads it back).
-    const bool unfolded = attn_unfolded();
     static const bool unfused_zsum = getenv("EV2H_ATTN_UNFUSED_ZSUM") != nullptr;
     bool zsum_fused = false;
-    if (!unfolded && !unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws) {
+    if (!unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws) {
         const Rng r0 = rg(R_L0, N);
         ev2h_gemm_desc d{};
         d.x_amax = r0.xa; d.x_amax2 = r0.xa2; d.x_group_rows = r0.xg;
@@ -691,19 +681,14 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     }
     if (!zsum_fused) {
         prof_begin("qconv0", st);
-        RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, attn_unfolded() ? rg(R_L0, N, R_Q1, N) : rg(R_L0, N), nullptr, 0, 0, 3, N));
+        RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N), nullptr, 0, 0, 3, N));
         prof_end("qconv0", st);
     }
     // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
-    // over the points (ev2h_attn_sim_folded): q2 is never formed
-    if (unfolded) {
-        for (int h = 0; h < 2; ++h)
-            RUN(dense(w->qconv4[h], ws.f("q1") + h * 256, 512, R, ws.f("q2") + (size_t)h * R * 256, 256, 0, st, rg(R_Q1, N), nullptr, 0, 0, 3, N));
-    }
+    // over the points (ev2h_attn_sim_folded): q2 is never formed.  (The unfolded form -- two more k = 3 GEMMs + ev2h_attn_sim -- is
+    // what the oracle computes; the operators stay in the ABI and are tested against it, tests/test_gpu_ops.py.)
     if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));              // logits ready
-    if (unfolded) {
-        RUN(ev2h_attn_sim(ws.f("logits_pm"), ws.f("q2"), 256, (size_t)R * 256, B, N, ws.f("sim"), st));
-    } else if (zsum_fused) {
+    if (zsum_fused) {
         RUN(ev2h_attn_simfold_partials(ws.f("zpart"), 128, ws.f("logits_pm"), B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
                                        ws.f("sim"), st));
     } else {

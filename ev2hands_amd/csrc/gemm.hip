@@ -378,8 +378,7 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->post_scale == nullptr) == (d->post_shift == nullptr));
     p.rowmax_rows = d->rowmax_rows;
     if (d->rowmax_rows) EV2H_CHECK_ARG(d->rowmax_rows == BM && d->M % BM == 0);
-    static const bool no_table = getenv("EV2H_NO_TABLE_KERNEL") != nullptr;       // A/B switch
-    if (!no_table && d->K == 8 && d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->post_scale && (d->N % 4) == 0 &&
+    if (d->K == 8 && d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->post_scale && (d->N % 4) == 0 &&
         (d->ldy % 4) == 0 && (d->ldx % 4) == 0 && (d->ldw % 4) == 0) {      // (any M: a result must not depend on the batch size)
         // write-bound K = 8 layer (the layer-1 tables of the raw cloud): exact fp32 fma chains in every precision mode
         TableP t{};
@@ -397,8 +396,7 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;
     }
-    static const bool no_skinny = getenv("EV2H_NO_SKINNY_KERNEL") != nullptr;      // A/B switch
-    if (d->skinny && !no_skinny) {
+    if (d->skinny) {
         EV2H_CHECK_ARG(d->taps == 1 && d->rowmax_rows == 0 && d->bias_group_rows == 0 && !d->y_scale);
         EV2H_CHECK_ARG(d->M <= 8 * 65535);                       // grid.y; the kernel is meant for M = number of windows anyway
         SkinnyP q{};

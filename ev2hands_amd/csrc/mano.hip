@@ -173,6 +173,9 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
         const float* wv = p.c.weights + v * NJ;
+        // (not unrolled further: fully unrolled, the compiler hoisted all 16 x 12 joint-transform values out of the vertex loop into
+        //  registers -- 192 values against a 128-register budget, 396 bytes of scratch per lane -- for a loop that runs once)
+#pragma unroll 2
         for (int k = 0; k < NJ; ++k) {
             const float w = wv[k];
 #pragma unroll
@@ -196,7 +199,12 @@ __global__ __launch_bounds__(MANO_THREADS) void mano_kernel(ManoP p) {
     if (tid < 21) {
         const int src = c_joint_reorder[tid];
         // (chain joints: the first part; a fingertip: the part that skinned its vertex)
-        const bool mine = (src < NJ) ? part == 0 : (p.c.tips[src - NJ] >= v_begin && p.c.tips[src - NJ] < v_end);
+        // (p.c.tips is a kernel-argument array: a run-time index into it made the compiler copy the whole argument block to
+        //  scratch -- 396 bytes per lane; the select chain keeps it in scalar registers)
+        int tipv = -1;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tipv = (src - NJ == t) ? p.c.tips[t] : tipv;
+        const bool mine = (src < NJ) ? part == 0 : (tipv >= v_begin && tipv < v_end);
         if (!mine) return;
         float j[3];
         for (int c = 0; c < 3; ++c) j[c] = (src < NJ) ? s_G[src][4 * c + 3] : s_tip[src - NJ][c];
@@ -218,8 +226,7 @@ extern "C" int ev2h_mano(const ev2h_mano_consts* c, const float* params, int ldp
     EV2H_CHECK_ARG((verts_stride == 0 || verts_stride >= (size_t)NV * 3) && (joints_stride == 0 || joints_stride >= 63));
     p.c = *c; p.params = params; p.ldp = ldp; p.verts = verts; p.joints = joints;
     p.verts_stride = verts_stride ? verts_stride : (size_t)NV * 3; p.joints_stride = joints_stride ? joints_stride : 63;
-    static const int forced_parts = getenv("EV2H_MANO_PARTS") ? atoi(getenv("EV2H_MANO_PARTS")) : 0;      // A/B switch
-    p.parts = forced_parts > 0 ? forced_parts : (B <= 32 ? 4 : 1);
+    p.parts = B <= 32 ? 4 : 1;      // a few windows at a time: a hand's vertices over four workgroups (tests: B = 1 .. 64 against the oracle)
     mano_kernel<<<B * p.parts, MANO_THREADS, 0, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

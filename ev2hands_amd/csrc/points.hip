@@ -374,17 +374,12 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     const size_t lds = (size_t)N * sizeof(float4);
     hipStream_t st = (hipStream_t)stream;
     const float4* p = (const float4*)pts4;
-    static const bool no_wide = getenv("EV2H_FPS_NO_WIDE") != nullptr;
     if (N > 2048 && N <= 8192) {   // > 32 KiB of points: raise the dynamic-LDS limit once
         static PerDevice attr_set{};
         EV2H_ONCE_PER_DEVICE(attr_set,
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<8, 512, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
             EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16, 512, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16));
-            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 16));
-            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fps_kernel<32>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16)););
     }
     if (N <= 256) fps_kernel<1><<<grid, 256, lds, st>>>(p, N, jobs);
@@ -393,11 +388,9 @@ extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const 
     else if (N <= 2048) fps_kernel<8><<<grid, 256, lds, st>>>(p, N, jobs);
     // N > 2048: the staged points (64 / 128 KB) leave two / one workgroup per CU, and with 16 / 32 points per thread the distance update
     // is most of a sampling step -- eight waves per window halve it (N = 2048 keeps four: there the exchange and the barrier dominate
-    // and sixteen waves measured slower).  Same maxima, same tie-break: identical indices.  EV2H_FPS_NO_WIDE=1: A/B.
-    else if (N <= 4096 && !no_wide) fps_kernel<8, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
-    else if (N <= 8192 && !no_wide) fps_kernel<16, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
-    else if (N <= 4096) fps_kernel<16><<<grid, 256, lds, st>>>(p, N, jobs);
-    else if (N <= 8192) fps_kernel<32><<<grid, 256, lds, st>>>(p, N, jobs);
+    // and sixteen waves measured slower).  Same maxima, same tie-break: identical indices.
+    else if (N <= 4096) fps_kernel<8, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
+    else if (N <= 8192) fps_kernel<16, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
     else if (N <= 16384) fps_kernel<16, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);      // beyond the LDS-resident sizes
     else fps_kernel<32, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);
     EV2H_CHECK_LAUNCH();
@@ -430,24 +423,17 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     // the L2 form (below) stages nothing, so a workgroup costs nothing to start: one centroid per wave -- a scan is a chain of
     // dependent L2 round trips with a data-dependent early exit, and many short waves hide both the latency and the imbalance
     // (16 windows of 8192 points, enc.sa1: 266 -> see DESIGN.md section 11; 32 centroids per workgroup left 8 scans in a row per wave)
-    static const int lds_max = getenv("EV2H_BALL_LDS_MAX") ? atoi(getenv("EV2H_BALL_LDS_MAX")) : 2048;
-    const bool l2_form = N > 8192 || N > lds_max;
+    constexpr int BALL_LDS_MAX = 2048;      // windows up to the reference's operating point are staged in LDS (measured neutral there)
+    const bool l2_form = N > BALL_LDS_MAX;
     if (l2_form) a.cpw = 4;
     a.nchunk = ceil_div(S, a.cpw);
     dim3 grid((unsigned)a.nchunk * (unsigned)B);
-    // Windows above EV2H_BALL_LDS_MAX points (default 2048: the reference's operating point keeps the LDS form, measured neutral there) read their points from L2 instead of staging them in LDS: at N = 8192 the
-    // 128 KB of staged points leave ONE 4-wave workgroup per CU, and the scan is latency-bound -- the L2 form is 3x faster there
-    // (1.74 -> ~0.5 ms per 128 windows; BASELINE config 5's shape +14.6 % windows/s, same-box A/B).  Same arithmetic, same results.
+    // Windows above BALL_LDS_MAX points are read through L2 instead of an LDS copy: at N = 8192 the 128 KB of staged points leave ONE
+    // 4-wave workgroup per CU and the scan is latency-bound (round 4: 3x faster, config 5's shape +14.6 %).  Same arithmetic, same results.
     if (l2_form) {
         ball_query_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;
-    }
-    if (N > 4096) {
-        static PerDevice attr_set{};
-        EV2H_ONCE_PER_DEVICE(attr_set,
-            EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_kernel<true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16)););
     }
     ball_query_kernel<true><<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
                                                                                              N, S, a);

@@ -1009,11 +1009,10 @@ int launch_sab(SaBP p, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
     {
         // small grids (a few windows at a time): spread a group's strips over the waves of a workgroup (SaBP::spg).  Chosen by the
-        // launch size only -- the result does not depend on it.  EV2H_SA_NO_SPREAD=1: A/B switch.
-        static const bool no_spread = getenv("EV2H_SA_NO_SPREAD") != nullptr;
+        // launch size only -- the result does not depend on it (a max is exact and order-free; operator tests at 1 .. 64 windows).
         const int spg = p.K / 32;
         p.spg = 1;
-        if (!no_spread && (spg == 2 || spg == 4) && p.nblk < 256 && SAB_WAVES * C3 * 4 <= 2 * Cfg::TILE) {
+        if ((spg == 2 || spg == 4) && p.nblk < 256 && SAB_WAVES * C3 * 4 <= 2 * Cfg::TILE) {
             p.spg = spg;
             p.nblk = ceil_div(p.B * p.S, SAB_WAVES / spg);
         }

@@ -103,6 +103,11 @@ class GatherBuffer:
     def __init__(self, N: int, global_batch: int, device, group=None):
         self.group, self.N = group, N
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # Transport of the one collective: RCCL ("nccl") moves device memory itself.  A process group without a device transport
+        # (gloo: the CPU tests, and tests/test_gpu_dist.py's two ranks that SHARE one GPU, which RCCL refuses) is served through a
+        # pinned host mirror of the buffer: D2H of this rank's slice, the same in-place all_gather_into_tensor on the mirror, H2D
+        # of the whole.  Only bytes move; the predictions are the forward's, bit for bit.
+        self.host_staged = torch.device(device).type == "cuda" and dist.get_backend(group) != "nccl"
         if global_batch < self.world:
             # a rank without a window would skip its forward (ev2h_forward needs B > 0) while the others wait in the collective:
             # refused here, on EVERY rank (the sizes are a pure function of global_batch and the world size)
@@ -111,6 +116,21 @@ class GatherBuffer:
         self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
         self.big = max(self.sizes)
         self.full = torch.zeros(self.world * self.big, packed_width(N), dtype=torch.float32, device=device)
+        self.host = torch.zeros(self.full.shape, dtype=torch.float32).pin_memory() if self.host_staged else None
+
+    def _gather(self, async_op: bool):
+        """the collective on whichever copy of the buffer the process group can move; returns (work or None)"""
+        lo = self.rank * self.big
+        if not self.host_staged:
+            return dist.all_gather_into_tensor(self.full, self.full[lo:lo + self.big], group=self.group, async_op=async_op)
+        self.host[lo:lo + self.big].copy_(self.full[lo:lo + self.big], non_blocking=True)
+        torch.cuda.current_stream(self.full.device).synchronize()          # the forward's rows have reached the mirror
+        return dist.all_gather_into_tensor(self.host, self.host[lo:lo + self.big], group=self.group, async_op=async_op)
+
+    def _landed(self):
+        """host-staged transport: the gathered mirror back onto the device (in stream order)"""
+        if self.host_staged:
+            self.full.copy_(self.host, non_blocking=True)
 
     def rows(self) -> torch.Tensor:
         lo = self.rank * self.big
@@ -118,8 +138,8 @@ class GatherBuffer:
         return self.full[lo:lo + self.sizes[self.rank]]
 
     def gather(self) -> dict:
-        lo = self.rank * self.big
-        dist.all_gather_into_tensor(self.full, self.full[lo:lo + self.big], group=self.group)
+        self._gather(async_op=False)
+        self._landed()
         if min(self.sizes) == self.big:
             return unpack_outputs(self.full, self.N)
         return unpack_outputs(torch.cat([self.full[r * self.big:r * self.big + self.sizes[r]] for r in range(self.world)], 0), self.N)
@@ -149,6 +169,7 @@ class GatherPipeline:
             if self.work is not None:
                 self.work.wait()                            # device-side: the current stream waits for the collective
                 self.work = None
+                self.buf._landed()
 
         def result(self) -> dict:
             if self.buf.generation != self.generation:
@@ -178,8 +199,7 @@ class GatherPipeline:
 
     def submit(self) -> "GatherPipeline.Pending":
         b = self.bufs[self.i]
-        lo = b.rank * b.big
-        work = dist.all_gather_into_tensor(b.full, b.full[lo:lo + b.big], group=b.group, async_op=True)
+        work = b._gather(async_op=True)
         p = self.pending[self.i] = GatherPipeline.Pending(b, work)
         self.i = (self.i + 1) % len(self.bufs)
         return p

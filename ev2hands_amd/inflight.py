@@ -1,0 +1,83 @@
+"""Several forwards in flight: throughput for batches that are too small to fill the chip on their own.
+
+A rank's share of BASELINE.json config 5 -- 128 dense windows over 8 GPUs -- is 16 windows of 8192 points.  One such forward is
+latency-bound for a fifth of its time: farthest point sampling is 512 DEPENDENT steps on 48 of the 256 CUs (~0.49 ms however few
+windows there are), followed by selection kernels that are chains of L2 round trips.  Consecutive batches are independent
+(eval-mode windows share nothing, /root/reference/src/Ev2Hands/model/TEHNet.py:168-197), so the head of batch i + 1 can run
+under the matrix-pipe-bound tail of batch i: `InflightForward` issues forward i on stream i mod depth with its own workspace.
+16 windows of 8192 points: 7 090 -> 8 560 windows/s with depth 2 (profiles/r5_inflight_n8192.txt); at 128 windows per GPU the
+chip is already full (+2.5 %), at the headline shape (256 windows of 2048 points) it is neutral -- the default is one in flight.
+
+Numbers are unchanged by construction: the same ev2h_forward with the same arguments, only on another stream
+(tests/test_gpu_forward.py::test_inflight_forwards_are_bit_identical).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class InflightForward:
+    """
+        pipe = InflightForward(net, depth=2)            # net: TEHNetWrapper (eval)
+        for batch in batches:
+            ticket = pipe.submit(batch)                 # returns at once; the forward runs on one of `depth` streams
+            ...
+            out = ticket.result()                       # the CURRENT stream waits (device-side) for that forward; dict as net(batch)
+        pipe.drain()
+
+    A slot (stream + workspace) is reused every `depth` submissions; submit() makes the slot's stream wait for the caller's
+    current stream first (the input is ready) and for the slot's previous forward by stream order.  `rows=` as in TEHNet.forward
+    (the multi-GPU gather buffer)."""
+
+    class Ticket:
+        def __init__(self, out, event):
+            self.out, self.event = out, event
+
+        def result(self) -> dict:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.event)
+            # the tensors were allocated on the slot's stream and are now used on the caller's: tell the caching allocator
+            for v in self.out.values():
+                for t in (v.values() if isinstance(v, dict) else (v,)):
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)
+            return self.out
+
+    def __init__(self, net, depth: int = 2):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        self.net, self.depth, self.i = net, depth, 0
+        self.streams, self.ws = None, [None] * depth
+
+    def _slot(self, device, nbytes: int):
+        if self.streams is None:
+            _lib.lib().ev2h_init()                      # the library's side stream first (it wants a hardware queue of its own)
+            self.streams = [torch.cuda.Stream(device) for _ in range(self.depth)]
+        k = self.i % self.depth
+        self.i += 1
+        if self.ws[k] is None or self.ws[k].numel() < nbytes:
+            self.ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self.streams[k], self.ws[k]
+
+    def submit(self, xyz: torch.Tensor, rows=None, post=None) -> "InflightForward.Ticket":
+        """post: optional callable(out) run right behind the forward ON THE SLOT'S STREAM (e.g. the collision term of the same
+        batch) -- work queued on the caller's stream instead would make the next submit() wait for it."""
+        B, _, N = xyz.shape
+        stream, ws = self._slot(xyz.device, _lib.lib().ev2h_workspace_bytes(B, N))
+        stream.wait_stream(torch.cuda.current_stream(xyz.device))
+        with torch.cuda.stream(stream), torch.no_grad():
+            out = self.net.net(xyz, self.net.hands, rows=rows, ws=ws)
+            if post is not None:
+                post(out)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        xyz.record_stream(stream)
+        return InflightForward.Ticket(out, ev)
+
+    def drain(self) -> None:
+        if self.streams:
+            cur = torch.cuda.current_stream()
+            for s in self.streams:
+                cur.wait_stream(s)

@@ -41,7 +41,8 @@ from ev2hands_amd import synth  # noqa: E402
 from oracle import make_golden, mano_oracle  # noqa: E402
 import trained_ckpt  # noqa: E402
 
-STEPS = int(os.getenv("EV2H_TRAIN_STEPS", "320"))
+STEPS = int(os.getenv("EV2H_TRAIN_STEPS", "480"))
+PHASE2 = 320          # from this step on the joint term is weighted 10 instead of 100 and the cross entropy 3 instead of 1
 STEPS_C5 = int(os.getenv("EV2H_TRAIN_STEPS_C5", "48"))
 BATCH, POINTS = 4, 2048
 STATE = "/tmp/ev2h_trained_state.pt"
@@ -90,16 +91,17 @@ def make_batch(C: int, step: int):
     return xyz, labels, targets
 
 
-def loss_fn(out, labels, targets, hands):
-    loss = F.cross_entropy(out["class_logits"], labels)
-    parts = {"ce": float(loss.detach())}
+def loss_fn(out, labels, targets, hands, w_ce=1.0, w_j3d=100.0):
+    ce = F.cross_entropy(out["class_logits"], labels)
+    loss = w_ce * ce
+    parts = {"ce": float(ce.detach())}
     for side in ("left", "right"):
         prm = torch.cat([out[side][k] for k in ("global_orient", "hand_pose", "betas", "transl")], 1)
         t = targets[side]
         lp = F.mse_loss(prm, t)
         with torch.no_grad():
             tj = hands[side](t[:, 0:3], t[:, 3:9], t[:, 9:19], t[:, 19:22]).joints
-        lj = F.mse_loss(out[side]["j3d"], tj) * 100.0
+        lj = F.mse_loss(out[side]["j3d"], tj) * w_j3d
         loss = loss + lp + lj
         parts[side + ".prm"] = float(lp.detach())
         parts[side + ".j3d"] = float(lj.detach())
@@ -126,7 +128,8 @@ def train_c4(te, hands, log):
     for step in range(start, STEPS):
         xyz, labels, targets = make_batch(4, step)
         out = net(xyz, hands)                                                     # train.py:83
-        loss, parts = loss_fn(out, labels, targets, hands)
+        # two phases: the joint term (huge at a random start) first, then the segmentation head gets its share of the gradient
+        loss, parts = loss_fn(out, labels, targets, hands, *((1.0, 100.0) if step < PHASE2 else (3.0, 10.0)))
         opt.zero_grad()                                                           # train.py:90-92
         loss.backward()
         opt.step()

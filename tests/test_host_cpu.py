@@ -387,3 +387,29 @@ def test_bench_launch_site_matching_is_independent_of_template_arguments():
     assert bench.site_dispatch_values("qconv0", [("fps_kernel<8>", 256, 1, 1.0)]) == []
     assert {s["tag"] for s in bench.launch_sites(8192)} == {"sa2.1", "qconv0"} and bench.launch_sites(8192)[0]["tag"] == "qconv0"
     assert bench.launch_sites(2048)[0]["tag"] == "sa2.1"
+
+
+def test_every_environment_switch_of_the_library_is_listed_in_the_gpu_switch_test():
+    """grep of csrc/: the set of getenv() names is exactly the tested set (a new switch must come with its test)."""
+    import re
+    from test_gpu_forward import AB_SWITCHES
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ev2hands_amd", "csrc")
+    found = set()
+    for fn in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))):
+        found |= set(re.findall(r'getenv\("(EV2H_[A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    found -= {"EV2H_PACK_HOST_ONLY"}          # not an A/B path: pack without a device (CPU layout tests)
+    assert found == {n for n, _, _ in AB_SWITCHES}, found ^ {n for n, _, _ in AB_SWITCHES}
+    assert len(found) <= 8
+
+
+def test_default_arithmetic_mode_is_auto(monkeypatch):
+    """A user who names no mode gets "auto" (f16x2 after a self-check against bf16x3 on the first batch); EV2H_PRECISION and
+    precision= still choose explicitly."""
+    from ev2hands_amd.model import TEHNetWrapper
+    monkeypatch.delenv("EV2H_PRECISION", raising=False)
+    assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
+    assert TEHNetWrapper("cpu", mano_assets=assets).net.precision == "auto"
+    assert TEHNetWrapper("cpu", mano_assets=assets, precision="bf16x3").net.precision == "bf16x3"
+    monkeypatch.setenv("EV2H_PRECISION", "f32")
+    assert TEHNetWrapper("cpu", mano_assets=assets).net.precision == "f32"
+    assert TEHNetWrapper("cpu", mano_assets=assets).net.AUTO_TOLERANCE == 5e-5

@@ -4,7 +4,7 @@ oracle/make_golden_trained.py ran the reference's own TEHNet (imported from /roo
 mode under Adam (lr 1e-3, /root/reference/src/Ev2Hands/train.py:22-23,53) starting from `synth_state_dict(4, INIT_SEED)`.
 What is committed is not the weights but what the optimiser did to them:
 
-  * every conv / linear weight with >= 1024 elements as a float16 DELTA on the hash-generated initial value
+  * every conv / linear weight matrix with >= 1024 elements as a float16 DELTA on the hash-generated initial value
     (`<key>::d16`; the checkpoint IS `init + float32(delta)`, evaluated here exactly as the generator evaluated it
     before it ran the reference's forward on it -- so the fixtures are outputs of the reference on exactly these
     float32 weights);
@@ -36,7 +36,7 @@ def encode(trained: "OrderedDict[str, torch.Tensor]", init: "OrderedDict[str, to
     """state dict -> arrays to store (generator side)."""
     out = {}
     for k, v in trained.items():
-        if v.dtype == torch.float32 and v.numel() >= DELTA_MIN_NUMEL and k in init and init[k].shape == v.shape:
+        if v.dtype == torch.float32 and v.dim() >= 2 and v.numel() >= DELTA_MIN_NUMEL and k in init and init[k].shape == v.shape:
             out[k + "::d16"] = (v - init[k]).numpy().astype(np.float16)
         else:
             out[k] = v.numpy()
@@ -49,7 +49,7 @@ def decode(arrays, init: "OrderedDict[str, torch.Tensor]") -> "OrderedDict[str, 
         if k + "::d16" in arrays:
             sd[k] = init[k] + torch.from_numpy(arrays[k + "::d16"].astype(np.float32))
         elif k in arrays:
-            sd[k] = torch.from_numpy(np.ascontiguousarray(arrays[k])).clone()
+            sd[k] = torch.from_numpy(np.array(arrays[k]))
         else:
             raise KeyError(k)
     return sd
@@ -63,7 +63,7 @@ def trained_state_dict(C: int = 4) -> "OrderedDict[str, torch.Tensor]":
     a5 = np.load(weights_path(5))
     sd5 = OrderedDict()
     for k, (shape, _kind) in synth.checkpoint_schema(5).items():
-        sd5[k] = torch.from_numpy(np.ascontiguousarray(a5[k])).clone() if k in a5.files else sd4[k].clone()
+        sd5[k] = torch.from_numpy(np.array(a5[k])) if k in a5.files else sd4[k].clone()
         assert tuple(sd5[k].shape) == tuple(shape), k
     return sd5
 

@@ -1,5 +1,5 @@
 """Two full batches in flight: step i on stream i % 2 with its own workspace and output buffers, so that the latency-bound head of
-step i+1 (sampling, ball queries, tables) can run under the MFMA-bound tail of step i.   python tools/debug/inflight.py [B]"""
+step i+1 (sampling, ball queries, tables) can run under the MFMA-bound tail of step i.   python tools/debug/inflight.py [B [N]]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ from ev2hands_amd import _lib, synth  # noqa: E402
 from ev2hands_amd.model import TEHNetWrapper  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-N, C = 2048, 4
+N, C = (int(sys.argv[2]) if len(sys.argv) > 2 else 2048), 4
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 os.environ["ERPC"] = "0"
