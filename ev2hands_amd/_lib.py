@@ -35,7 +35,8 @@ class SaDesc(C.Structure):
                 ("C1", ci), ("C2", ci), ("C3", ci), ("precision", ci), ("W2s", vp), ("W3s", vp), ("cnt", vp), ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("cnt_ld", ci),
                 ("p1_scale", vp), ("p1_amax", vp), ("w1x_norm", C.c_float), ("dmax", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
                 ("out_amax", vp), ("feat", vp), ("ldf", ci), ("W1f", vp), ("ldw1f", ci), ("b1", vp), ("nfeat", ci),
-                ("feat_amax", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float), ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float)]
+                ("feat_amax", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float), ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float),
+                ("xyz_out", vp), ("xyz_ld", ci)]
 
 
 class FpDesc(C.Structure):
@@ -80,7 +81,7 @@ class TensorDesc(C.Structure):
 DT_F32, DT_F64, DT_I64 = 0, 1, 2
 PACK_EQUALIZE, PACK_HOST_ONLY, PACK_UNEQUALIZED_OK = 1, 2, 4
 W_EQUALIZED, W_UNEQUALIZED_OK = 1, 2
-ABI_VERSION = 6     # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs; 6: ev2h_pack_weights, ev2h_weights.flags
+ABI_VERSION = 7     # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs; 6: ev2h_pack_weights, ev2h_weights.flags; 7: ev2h_sa_desc.xyz_out
 
 PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
 

@@ -135,18 +135,6 @@ int ev2h_attn_simfold_partials(const float* zpart, int rows_per_partial, const f
 
 namespace {
 
-// dst[row][col..col+7] = (x, y, z, 0, 0, 0, 0, 0): the raw-xyz columns of a group-all input
-// (pointnet2_utils.py:155 concatenates [xyz, features]; our packed weights use [features | xyz | pad]).
-__global__ __launch_bounds__(256) void write_xyz_cols_kernel(const float4* __restrict__ src4, size_t rows, float* __restrict__ dst,
-                                                             int ld, int col) {
-    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const float4 v = src4[r];
-    float4* o = reinterpret_cast<float4*>(dst + r * ld + col);
-    o[0] = make_float4(v.x, v.y, v.z, 0.f);
-    o[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 // ---------------------------------------------------------------------------------------- workspace layout
 struct Buf {
     const char* name;
@@ -329,7 +317,7 @@ static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
 static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,
                        const int32_t* cnt, int B, int Npts, const float* P1, float* out, int ldo, ev2h_stream_t st, bool ranges,
                        const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax, const float* feat = nullptr, int nfeat = 0,
-                       const uint32_t* feat_amax = nullptr) {
+                       const uint32_t* feat_amax = nullptr, float* xyz_out = nullptr, int xyz_ld = 0) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     int coff1 = 0, coff3 = 0;
@@ -352,7 +340,8 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
             d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
         }
-        d.cnt = cnt ? cnt + i : nullptr; d.cnt_ld = m.nbranch;      // padding-only strips are skipped (bit-identical: test_sa_mlp_max_padding_skip)
+        d.cnt = cnt ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
+        if (i == 0 && xyz_out) { d.xyz_out = xyz_out; d.xyz_ld = xyz_ld; }      // the consumer's raw-xyz columns: written once, by the first branch      // padding-only strips are skipped (bit-identical: test_sa_mlp_max_padding_skip)
         char t[40];
         snprintf(t, sizeof(t), "%s.%d", tag, i);
         prof_begin(t, st);
@@ -366,10 +355,11 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
 
 static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, const float* feat, int ldf, const float* pts4, const float* ctr4,
                      int32_t* const* gidx, const int32_t* cnt, int B, int Npts, float* P1, float* out, int ldo, ev2h_stream_t st,
-                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax, int nfeat = 0) {
+                     const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, uint32_t* out_amax, int nfeat = 0, float* xyz_out = nullptr,
+                     int xyz_ld = 0) {
     if (!bf16_direct_layer1(precision, m)) RUN(sa_table(precision, m, feat, ldf, B, Npts, P1, st, feat_amax, p1_amax, p1_scale));
     return sa_branches(precision, tag, m, pts4, ctr4, gidx, cnt, B, Npts, P1, out, ldo, st, feat_amax != nullptr, p1_amax, p1_scale, out_amax,
-                       ldf == 8 ? feat : nullptr, nfeat, feat_amax);
+                       ldf == 8 ? feat : nullptr, nfeat, feat_amax, xyz_out, xyz_ld);
 }
 
 }  // namespace
@@ -584,10 +574,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         const ev2h_sa_module& m = w->sa2;
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[8], 0));
         RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi2, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
-                      ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2)));
-        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)st>>>((const float4*)ws.f("ctr2"), (size_t)B * 128,
-                                                                                   ws.f("l2buf"), 520, 512);
-        EV2H_CHECK_LAUNCH();
+                      ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2), 0, ws.f("l2buf") + 512, 520));      // + the xyz columns of enc.sa3's input
     }
     // ---- enc.sa3 group-all (TEHNet.py:181): 515 -> 256 -> 512 -> 1024, max over the 128 points
     // (the xyz columns of l2buf are input coordinates: the input's record R_FEAT bounds them)
@@ -708,14 +695,11 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
         RUN(sa_module(prec, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh,
-                      ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h), 4));
-        write_xyz_cols_kernel<<<ceil_div(B * 128, 256), 256, 0, (hipStream_t)sh>>>((const float4*)ws.f(nm[2]), (size_t)B * 128,
-                                                                                   ws.f(nm[6]), 520, 512);
-        EV2H_CHECK_LAUNCH();
+                      ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h), 4, ws.f(nm[6]) + 512, 520));   // + the xyz columns of the regressor's sa2 input
         RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh, rg(R_M1 + h, 128, R_MSA2H + h, 128, R_FEAT)));
         RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, rg(R_MSA2H + h, 128, R_M2 + h, 1), nullptr, 0, 0, 1, 0, 128));
         RUN(dense(w->head0[h], ws.f(nm[8]), 512, B, ws.f(nm[9]), 1024, 1, sh, rg(R_M2 + h, 1, R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
-        const int ldprm = out->params_stride ? (int)out->params_stride : 22;
+        const int ldprm = out->params_stride ? (int)out->params_stride : w->head4[h].O;
         RUN(dense(w->head4[h], ws.f(nm[9]), 1024, B, out->params[h], ldprm, 0, sh, rg(R_FC1 + h, 1), nullptr, 0, 0, 1, 0, 0, 1));
         if (mano[h]) RUN(ev2h_mano(mano[h], out->params[h], ldprm, B, out->vertices[h], out->vertices_stride, out->joints[h], out->joints_stride, sh));
     }
@@ -731,7 +715,17 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     // a NULL hand model skips that hand's MANO layer (the caller applies its own to params[h], TEHNet.py:103)
     EV2H_CHECK_ARG(!mano_left || (out->vertices[0] && out->joints[0]));
     EV2H_CHECK_ARG(!mano_right || (out->vertices[1] && out->joints[1]));
-    EV2H_CHECK_ARG((out->logits_stride == 0 || out->logits_stride >= (size_t)4 * N) && (out->params_stride == 0 || out->params_stride >= 22));
+    EV2H_CHECK_ARG((out->logits_stride == 0 || out->logits_stride >= (size_t)4 * N) && (out->params_stride == 0 || out->params_stride >= (size_t)w->head4[0].O));
+    // the head's width 3 + n_pose_params + 10 + 3 comes from the checkpoint (ev2h_pack_weights); a hand model must take that many PCA coefficients
+    EV2H_CHECK_ARG(w->head4[0].O == w->head4[1].O && w->head4[0].O >= 17 && w->head4[0].O <= 61);
+    for (int h = 0; h < 2; ++h) {
+        const ev2h_mano_consts* mc = h ? mano_right : mano_left;
+        if (mc && 3 + mc->ncomps + 13 != w->head4[h].O) {
+            ev2h_set_error("ev2h_forward: the checkpoint regresses %d pose coefficients per hand, the %s MANO model takes %d", w->head4[h].O - 16,
+                           h ? "right" : "left", mc->ncomps);
+            return EV2H_ERR_ARG;
+        }
+    }
     EV2H_CHECK_ARG(out->params_stride <= 0x7fffffff);
     EV2H_CHECK_ARG((out->vertices_stride == 0 || out->vertices_stride >= 2334) && (out->joints_stride == 0 || out->joints_stride >= 63));
     EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);

@@ -42,7 +42,10 @@ const MsgSpec SA2 = {2, {{128, 128, 256}, {128, 196, 256}, {0, 0, 0}}, {0.4, 0.8
 const MsgSpec MANO_SA1 = SA2;
 const int SA3_MLP[3] = {256, 512, 1024}, FP3_MLP[2] = {256, 256}, FP2_MLP[2] = {256, 128}, FP1_MLP[3] = {128, 128, 256};
 const int MANO_SA2_MLP[2] = {256, 512};
-const int N_MANO_OUT = 22, N_CLASSES = 4;
+const int N_CLASSES = 4;
+// the regression head's width 3 + n_pose_params + 10 + 3 (TEHNet.py:49-55,87-90) is read off the checkpoint: TEHNet(n_pose_params)
+// takes any number of MANO PCA coefficients (TEHNet.py:114-125; the MANO layer has at most 45)
+const int MANO_OUT_MIN = 3 + 1 + 10 + 3, MANO_OUT_MAX = 3 + 45 + 10 + 3;
 const char* const SIDES[2] = {"left", "right"};
 const double BN_EPS = 1e-5;
 
@@ -51,6 +54,11 @@ struct Tensor { Vec v; std::vector<int64_t> shape; bool used = false; };
 
 struct Ckpt {
     std::map<std::string, Tensor> t;
+    // first dimension of a tensor (the widths that the checkpoint, not the schema, decides), 0 if the key is absent (get() reports it)
+    int64_t dim0(const std::string& key) const {
+        auto it = t.find(key);
+        return (it == t.end() || it->second.shape.empty()) ? 0 : it->second.shape[0];
+    }
     const Vec& get(const std::string& key, std::initializer_list<int64_t> shape) {
         auto it = t.find(key);
         if (it == t.end()) fail("ev2h_pack_weights: missing key \"%s\" in the checkpoint", key.c_str());
@@ -162,7 +170,9 @@ Folded fold_checkpoint(Ckpt& ck, int in_channels) {
         fold_msg(ck, F, p + ".sa1", MANO_SA1, 4 + 3);
         fold_stack(ck, F, p + ".sa2", MANO_SA2_MLP, 2, 512 + 3, 2);
         F[p + ".head0"] = post_conv(ck, p + ".mano_regressor.0", p + ".mano_regressor.2", 1024, 512, 0);
-        F[p + ".head4"] = plain_conv(ck, p + ".mano_regressor.4", N_MANO_OUT, 1024, 0);
+        int n_out = (int)ck.dim0("left_mano_regressor.mano_regressor.4.weight");        // both hands: the same n_pose_params (TEHNet.py:144-145)
+        if (n_out < MANO_OUT_MIN || n_out > MANO_OUT_MAX) n_out = 3 + 6 + 10 + 3;         // (absent / out of range: get() names the key and the expected default)
+        F[p + ".head4"] = plain_conv(ck, p + ".mano_regressor.4", n_out, 1024, 0);
     }
     return F;
 }

@@ -34,6 +34,7 @@ struct SaP {
     float* out; int ldo;
     int B, Npts, S, K;
     int nblk;
+    float* xyz_out; int xyz_ld;          // optional: the group's centroid as 8 more columns of the consumer's input rows (ev2h_sa_desc)
 };
 
 constexpr int SA_WAVES = 8;
@@ -242,6 +243,10 @@ __global__ __launch_bounds__(SA_THREADS, 2) void sa_mlp_max_kernel(SaP p) {
         const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
         if (valid && half == 0) p.out[(size_t)g * p.ldo + 32 * u + l31] = fmaxf(v + p.b3[32 * u + l31], 0.f);
     }
+    if (p.xyz_out && valid && lane < 8) {
+        const float4 c = p.ctr4[g];
+        p.xyz_out[(size_t)g * p.xyz_ld + lane] = lane == 0 ? c.x : lane == 1 ? c.y : lane == 2 ? c.z : 0.f;
+    }
 }
 
 template <int C1, int C2, int C3>
@@ -265,6 +270,7 @@ extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d && (d->P1 || d->feat) && d->pts4 && d->ctr4 && d->gidx && d->W1x && d->b2 && d->b3 && d->out);
     EV2H_CHECK_ARG(d->B > 0 && d->S > 0 && d->Npts > 0 && d->K >= 32 && (d->K % 32) == 0);
     EV2H_CHECK_ARG((d->ldp % 4) == 0);
+    EV2H_CHECK_ARG(!d->xyz_out || (d->xyz_ld >= 8 && (d->xyz_ld % 4) == 0));
     if (d->precision != EV2H_PREC_F32) return ev2h_sa_mlp_max_bf16(d, stream);
     // exact fp32: layer 1 is the gathered table row + the relative-coordinate term; the raw-feature form (ev2h_sa_desc.feat
     // without a table) exists on the matrix pipe only
@@ -278,6 +284,7 @@ extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.W1x = (const float4*)d->W1x; p.W2 = d->W2; p.b2 = d->b2; p.W3 = d->W3; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
     p.nblk = ceil_div(d->B * d->S, SA_WAVES);
+    p.xyz_out = d->xyz_out; p.xyz_ld = d->xyz_ld;
     hipStream_t st = (hipStream_t)stream;
     const int c1 = d->C1, c2 = d->C2, c3 = d->C3;
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sa<32, 32, 64>(p, st);

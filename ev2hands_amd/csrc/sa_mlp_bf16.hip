@@ -62,6 +62,7 @@ struct SaBP {
     // the result is bit-identical; the weights are streamed once per strip SET instead of once per strip of the longest group.
     // One window at a time (demo.py:24-33) has 16 workgroups for 256 CUs in the 128-centroid modules: 88 -> ~25 us per launch.
     int spg;
+    float* xyz_out; int xyz_ld;            // optional: the group's centroid as 8 more columns of the consumer's input rows (ev2h_sa_desc)
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -936,6 +937,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
         }
     }
+    if constexpr (!ROWS) {
+        if (p.xyz_out && valid && sw == 0 && lane < 8)
+            p.xyz_out[(size_t)g * p.xyz_ld + lane] = lane == 0 ? ctr.x : lane == 1 ? ctr.y : lane == 2 ? ctr.z : 0.f;
+    }
     if constexpr (NS == 2) {
         // Range record of the output (ev2hands_hip.h "Range records"): amax[b] = max over the window's groups.  One device-scope
         // atomicMax per GROUP put 512 read-modify-writes on one address per window and launch; across the 8 XCDs these are
@@ -1132,6 +1137,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.W1x = (const float4*)d->W1x; p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
     p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
+    p.xyz_out = d->xyz_out; p.xyz_ld = d->xyz_ld;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     if (d->feat) {

@@ -16,8 +16,8 @@ from . import synth
 PER_HAND = synth.N_MANO_OUT + synth.MANO_NV * 3 + 21 * 3      # 22 + 2334 + 63
 
 
-def packed_width(N: int) -> int:
-    return 4 * N + 2 * PER_HAND
+def packed_width(N: int, n_pose: int = synth.MANO_CMPS) -> int:
+    return 4 * N + 2 * (PER_HAND + n_pose - synth.MANO_CMPS)
 
 
 def shard_range(global_batch: int, rank: int, world: int):
@@ -80,15 +80,16 @@ def all_gather_outputs(out: dict, N: int, group=None, global_batch: int | None =
     if sizes[rank] != local.shape[0]:
         raise ValueError(f"rank {rank}: local batch {local.shape[0]} is not this rank's shard of {sizes} windows")
     big = max(sizes)
+    n_pose = out["left"]["hand_pose"].shape[1]
     if min(sizes) == big:
         full = torch.empty(world * big, local.shape[1], device=local.device, dtype=local.dtype)
         dist.all_gather_into_tensor(full, local, group=group)
-        return unpack_outputs(full, N)
+        return unpack_outputs(full, N, n_pose)
     padded = local if local.shape[0] == big else torch.cat([local, local.new_zeros(big - local.shape[0], local.shape[1])], 0)
     full = torch.empty(world * big, local.shape[1], device=local.device, dtype=local.dtype)
     dist.all_gather_into_tensor(full, padded.contiguous(), group=group)
     rows = torch.cat([full[r * big:r * big + sizes[r]] for r in range(world)], 0)
-    return unpack_outputs(rows, N)
+    return unpack_outputs(rows, N, n_pose)
 
 
 class GatherBuffer:
@@ -100,8 +101,8 @@ class GatherBuffer:
     concatenation, no per-step allocation.  Unequal shards: a short shard leaves the tail of its slice unused and `gather()`
     trims it (the only case that copies)."""
 
-    def __init__(self, N: int, global_batch: int, device, group=None):
-        self.group, self.N = group, N
+    def __init__(self, N: int, global_batch: int, device, group=None, n_pose: int = synth.MANO_CMPS):
+        self.group, self.N, self.n_pose = group, N, n_pose
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         # Transport of the one collective: RCCL ("nccl") moves device memory itself.  A process group without a device transport
         # (gloo: the CPU tests, and tests/test_gpu_dist.py's two ranks that SHARE one GPU, which RCCL refuses) is served through a
@@ -115,7 +116,7 @@ class GatherBuffer:
         self.generation = 0          # bumped whenever rows() hands the buffer to a new forward (GatherPipeline.Pending checks it)
         self.sizes = [hi - lo for lo, hi in (shard_range(global_batch, r, self.world) for r in range(self.world))]
         self.big = max(self.sizes)
-        self.full = torch.zeros(self.world * self.big, packed_width(N), dtype=torch.float32, device=device)
+        self.full = torch.zeros(self.world * self.big, packed_width(N, n_pose), dtype=torch.float32, device=device)
         self.host = torch.zeros(self.full.shape, dtype=torch.float32).pin_memory() if self.host_staged else None
 
     def _gather(self, async_op: bool):
@@ -141,8 +142,8 @@ class GatherBuffer:
         self._gather(async_op=False)
         self._landed()
         if min(self.sizes) == self.big:
-            return unpack_outputs(self.full, self.N)
-        return unpack_outputs(torch.cat([self.full[r * self.big:r * self.big + self.sizes[r]] for r in range(self.world)], 0), self.N)
+            return unpack_outputs(self.full, self.N, self.n_pose)
+        return unpack_outputs(torch.cat([self.full[r * self.big:r * self.big + self.sizes[r]] for r in range(self.world)], 0), self.N, self.n_pose)
 
 
 class GatherPipeline:
@@ -179,15 +180,15 @@ class GatherPipeline:
             if self._out is None:
                 b = self.buf
                 if min(b.sizes) == b.big:
-                    self._out = unpack_outputs(b.full, b.N)
+                    self._out = unpack_outputs(b.full, b.N, b.n_pose)
                 else:
-                    self._out = unpack_outputs(torch.cat([b.full[r * b.big:r * b.big + b.sizes[r]] for r in range(b.world)], 0), b.N)
+                    self._out = unpack_outputs(torch.cat([b.full[r * b.big:r * b.big + b.sizes[r]] for r in range(b.world)], 0), b.N, b.n_pose)
             return self._out
 
-    def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2):
+    def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2, n_pose: int = synth.MANO_CMPS):
         if depth < 1:
             raise ValueError("depth >= 1")
-        self.bufs = [GatherBuffer(N, global_batch, device, group) for _ in range(depth)]
+        self.bufs = [GatherBuffer(N, global_batch, device, group, n_pose) for _ in range(depth)]
         self.pending = [None] * depth
         self.i = 0
 

@@ -78,8 +78,14 @@ class TEHNet(nn.Module):
 
     def __init__(self, n_pose_params, num_classes=4):
         super().__init__()
-        if num_classes != 4 or n_pose_params != synth.MANO_CMPS:
-            raise ValueError("the HIP path is built for num_classes=4, n_pose_params=6 (settings.MANO_CMPS)")
+        # n_pose_params: any number of MANO PCA coefficients (TEHNet.py:114-125; the reference's settings use 6, the layer has 45).
+        # num_classes: the reference's own forward only runs with 4 -- the attention context has num_classes channels
+        # (TEHNet.py:13-27) and MANORegressor is built for n_inp_features = 4 of them (TEHNet.py:31,144-145), so another value
+        # raises inside its first regressor convolution
+        if num_classes != 4:
+            raise ValueError("num_classes must be 4: the reference's MANORegressor takes the attention's 4 class channels (TEHNet.py:31,144-145)")
+        if not 1 <= int(n_pose_params) <= 45:
+            raise ValueError("n_pose_params must be 1 .. 45 (MANO has 45 pose PCA components)")
         self.in_channels = 3 + 1 + int(os.getenv("ERPC", 0))
         self.n_pose_params = n_pose_params
         self.sa1 = _MsgParams(self.in_channels + 3, synth.SA1_MLPS)
@@ -219,7 +225,7 @@ class TEHNet(nn.Module):
 
         f32 = dict(device=device, dtype=torch.float32)
         out = _lib.Outputs()
-        NP, NVF = synth.N_MANO_OUT, synth.MANO_NV * 3
+        NP, NVF = 3 + self.n_pose_params + 10 + 3, synth.MANO_NV * 3
         if rows is None:
             logits = torch.empty(B, 4, N, **f32)
             params = [torch.empty(B, NP, **f32) for _ in range(2)]
@@ -474,8 +480,11 @@ class TEHNetWrapper:
     """model.py:10-64.  `mano_assets` / `mano_path` say where the MANO constants come from (the
     reference reads settings.MANO_PATH, which cannot be imported without pyrender)."""
 
-    def __init__(self, device, mano_path="../data/models", mano_assets=None, precision=None):
-        self.net = TEHNet(n_pose_params=synth.MANO_CMPS).to(device)
+    def __init__(self, device, mano_path="../data/models", mano_assets=None, precision=None, n_pose_params=None):
+        # n_pose_params: the reference reads settings.MANO_CMPS (= 6, model.py:52-55); another value (1 .. 45) is an extension of
+        # the constructor only -- checkpoint head width, MANO layer and the `rows=` layout follow it
+        n_pose = synth.MANO_CMPS if n_pose_params is None else int(n_pose_params)
+        self.net = TEHNet(n_pose_params=n_pose).to(device)
         if precision is not None:           # otherwise EV2H_PRECISION, default "auto" (f16x2 after a self-check on the first batch)
             self.net.precision = precision
         self.net.eval()
@@ -485,7 +494,7 @@ class TEHNetWrapper:
             # hardware queue (ev2h_init)
             with torch.cuda.device(device):
                 _lib.check(_lib.lib().ev2h_init(), "ev2h_init")
-        self.hands = create_mano_layers(mano_path, device, synth.MANO_CMPS, assets=mano_assets)
+        self.hands = create_mano_layers(mano_path, device, n_pose, assets=mano_assets)
         self.rot = _rotation_x_180().to(device).float()
 
     def state_dict(self):

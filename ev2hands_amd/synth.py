@@ -85,7 +85,7 @@ N_CLASSES = 4
 N_MANO_OUT = 3 + MANO_CMPS + 10 + 3
 
 
-def checkpoint_schema(in_channels: int = 4) -> "OrderedDict[str, tuple]":
+def checkpoint_schema(in_channels: int = 4, n_pose: int = MANO_CMPS) -> "OrderedDict[str, tuple]":
     """name -> (shape, kind) for all 342 state_dict entries, in module order.
 
     kind in {conv_w, conv_b, bn_w, bn_b, bn_mean, bn_var, bn_count}.
@@ -137,7 +137,7 @@ def checkpoint_schema(in_channels: int = 4) -> "OrderedDict[str, tuple]":
         stack(p + ".sa2", 512 + 3, MANO_SA2_MLP, (1, 1))
         conv(p + ".mano_regressor.0", 1024, 512, ())
         bn(p + ".mano_regressor.2", 1024)
-        conv(p + ".mano_regressor.4", N_MANO_OUT, 1024, ())
+        conv(p + ".mano_regressor.4", 3 + n_pose + 10 + 3, 1024, ())
     for side in ("left", "right"):
         p = f"{side}_query_conv"
         conv(p + ".0", 256, 256, (3,))
@@ -147,11 +147,11 @@ def checkpoint_schema(in_channels: int = 4) -> "OrderedDict[str, tuple]":
     return sch
 
 
-def synth_state_dict(in_channels: int = 4, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+def synth_state_dict(in_channels: int = 4, seed: int = 0, n_pose: int = MANO_CMPS) -> "OrderedDict[str, torch.Tensor]":
     """Random-init checkpoint with non-trivial BN running stats:
     conv/linear ~ U(+-1/sqrt(fan_in)), gamma in [.5,1.5], beta, mean ~ N(0,.1), var in [.5,1.5]."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for name, (shape, kind) in checkpoint_schema(in_channels).items():
+    for name, (shape, kind) in checkpoint_schema(in_channels, n_pose).items():
         if kind == "conv_w":
             fan_in = int(np.prod(shape[1:]))
             v = (hash_uniform(name, shape, seed) * 2 - 1) / np.sqrt(fan_in)

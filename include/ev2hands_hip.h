@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 6
+#define EV2H_ABI_VERSION 7
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -215,6 +215,10 @@ typedef struct ev2h_sa_desc {
     int nfeat;
     const uint32_t* feat_amax;
     float w1f_norm, b1_max, w1f_unscale, w1x_unscale;
+    /* optional (ABI 7): also write every group's centroid as (x, y, z, 0, 0, 0, 0, 0) to xyz_out[(b * S + s) * xyz_ld .. + 8) -- the
+     * raw-xyz columns of the group-all layer that consumes `out` (model/pointnet2_utils.py:155 concatenates [xyz, features]; the
+     * forward's buffers hold [features | xyz | pad]), which used to take a launch of their own per module.  xyz_ld % 4 == 0.     */
+    float* xyz_out; int xyz_ld;
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 
@@ -504,7 +508,7 @@ float ev2h_plane_unscale(const double* W, size_t count, int planes);
 
 typedef struct ev2h_outputs {
     float* class_logits;          /* [B,4,N]                                                           */
-    float* params[2];             /* [B][22]   left, right                                             */
+    float* params[2];             /* [B][P] left, right; P = 3 + n_pose_params + 10 + 3: the checkpoint's head width (22)  */
     float* vertices[2];           /* [B][778][3]                                                       */
     float* joints[2];             /* [B][21][3]                                                        */
     /* Floats between consecutive WINDOWS of each output (0 = dense: 4N, 22, 2334, 63).  With all four set to one row width the

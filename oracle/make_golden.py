@@ -38,6 +38,8 @@ CASES = [
     ("E_c4_n8192", "E", 4, 8192, 1, 4),      # BASELINE.json config 5 window size
     ("E_c5_n256_mhlnes", "E", 5, 256, 2, 6),  # MHLNES=1 (TEHNet.py:148,176-177): channel 2 overwritten in place (name suffix)
     ("E_c4_n2048_ties", "E", 4, 2048, 2, 31),  # near-tie segmentation head (oracle/stress.py: near_tie_state_dict, eps 0.3)
+    ("E_c4_n256_pose12", "E", 4, 256, 2, 8),   # TEHNet(n_pose_params=12) (TEHNet.py:114-125; name suffix _pose<K>): head width 28
+    ("U_c5_n256_pose45", "U", 5, 256, 2, 9),   # all 45 MANO pose components: head width 61
 ]
 TIE_EPS = 0.3
 
@@ -72,12 +74,13 @@ def run_case(pn, te, name, kind, C, N, B, seed, sd_override=None, extra=None):
     os.environ["ERPC"] = "1" if C == 5 else "0"
     mhlnes = name.endswith("_mhlnes")
     os.environ["MHLNES"] = "1" if mhlnes else "0"
-    sd = synth.synth_state_dict(C, seed) if sd_override is None else sd_override
-    net = te.TEHNet(n_pose_params=synth.MANO_CMPS)
+    n_pose = int(name.rsplit("_pose", 1)[1]) if "_pose" in name else synth.MANO_CMPS
+    sd = synth.synth_state_dict(C, seed, n_pose) if sd_override is None else sd_override
+    net = te.TEHNet(n_pose_params=n_pose)
     assert net.mhlnes == int(mhlnes)
     net.load_state_dict(sd, strict=True)
     net.eval()
-    hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
+    hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed), ncomps=n_pose)
     xyz = synth.synth_cloud(kind, B, C, N, seed)
     inits = synth.fps_inits(B, N, seed)
     if name.endswith("_ties"):
@@ -141,7 +144,7 @@ def run_case(pn, te, name, kind, C, N, B, seed, sd_override=None, extra=None):
     trace = {}
     xyz_mine_in = xyz.clone()
     with torch.no_grad():
-        mine = tehnet_oracle.tehnet_forward(sd, xyz_mine_in, hands, fps_init=inits, trace=trace, mhlnes=mhlnes)
+        mine = tehnet_oracle.tehnet_forward(sd, xyz_mine_in, hands, fps_init=inits, trace=trace, mhlnes=mhlnes, n_pose=n_pose)
     assert torch.equal(xyz_mine_in, xyz_ref_in), "oracle leaves a different input behind than the reference"
     assert torch.equal(xyz_ref_in, xyz) != mhlnes, "MHLNES must (only) mutate the input when set"
     assert torch.equal(mine["class_logits"], ref["class_logits"]), "oracle != reference (logits)"
@@ -166,6 +169,7 @@ def run_case(pn, te, name, kind, C, N, B, seed, sd_override=None, extra=None):
         "kind": np.array(kind),
         "xyz": xyz.numpy(),
         "mhlnes": np.array(int(mhlnes)),
+        "n_pose": np.array(n_pose),
         "xyz_after": xyz_ref_in.numpy() if mhlnes else np.zeros(0, dtype=np.float32),
         "fps_init": torch.stack(inits).numpy().astype(np.int32),
         "class_logits": ref["class_logits"].numpy(),

@@ -45,24 +45,25 @@ def nn_mismatches(query, known, got, want):
     return int((~(same_pts | same_dist)).any(-1).sum())
 
 
-def make_net(C, seed, device="cuda:0", precision="f32", sd=None):
+def make_net(C, seed, device="cuda:0", precision="f32", sd=None, n_pose=None):
     from ev2hands_amd.model import TEHNetWrapper
     os.environ["ERPC"] = "1" if C == 5 else "0"
     os.environ["EV2H_PRECISION"] = precision
     assets = {s: synth.synth_mano_assets(s, seed) for s in ("left", "right")}
-    sd = synth.synth_state_dict(C, seed) if sd is None else sd
-    net = TEHNetWrapper(device, mano_assets=assets)
+    sd = (synth.synth_state_dict(C, seed) if n_pose is None else synth.synth_state_dict(C, seed, n_pose)) if sd is None else sd
+    net = TEHNetWrapper(device, mano_assets=assets, n_pose_params=n_pose)
     net.load_state_dict(sd, strict=True)
     net.eval()
     return net, sd, assets
 
 
-def run_oracle(sd, assets, xyz, inits):
+def run_oracle(sd, assets, xyz, inits, n_pose=None):
     from oracle import mano_oracle, tehnet_oracle
-    hands = mano_oracle.make_hands(assets["left"], assets["right"])
+    n_pose = synth.MANO_CMPS if n_pose is None else n_pose
+    hands = mano_oracle.make_hands(assets["left"], assets["right"], ncomps=n_pose)
     trace = {}
     with torch.no_grad():
-        out = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=trace)
+        out = tehnet_oracle.tehnet_forward(sd, xyz.clone(), hands, fps_init=inits, trace=trace, n_pose=n_pose)
     return out, trace
 
 
@@ -200,8 +201,9 @@ def run_reference_fixture(path, precision, sd=None):
     B, C, N, seed = [int(v) for v in g["meta"]]
     mhlnes = bool(int(g["mhlnes"])) if "mhlnes" in g.files else False
     os.environ["MHLNES"] = "1" if mhlnes else "0"          # read at construction, like TEHNet.py:148
+    n_pose = int(g["n_pose"]) if "n_pose" in g.files else None              # TEHNet(n_pose_params): fixtures *_pose<K>
     try:
-        net, sd, assets = make_net(C, seed, precision=precision, sd=sd)
+        net, sd, assets = make_net(C, seed, precision=precision, sd=sd, n_pose=n_pose)
     finally:
         os.environ["MHLNES"] = "0"
     assert net.net.mhlnes == int(mhlnes)
@@ -806,3 +808,38 @@ def test_inflight_forwards_are_bit_identical(precision, B, N):
                     assert torch.equal(g_, w_), (depth, rep, i)
         pipe.drain()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x2"])
+@pytest.mark.parametrize("n_pose,C", [(1, 4), (12, 5), (45, 4)])
+def test_forward_with_other_pose_widths(n_pose, C, precision):
+    """TEHNet(n_pose_params) takes any number of MANO PCA coefficients (TEHNet.py:114-125): the head is 3 + n_pose + 10 + 3 wide,
+    the MANO layer takes n_pose components, the `rows=` layout follows.  Against the oracle at the full parity bar, and through
+    the gather-buffer layout (ev2hands_amd/dist.py: packed_width / unpack_outputs with n_pose)."""
+    _need_gpu()
+    from ev2hands_amd import dist as evdist
+    B, N, seed = 2, 512, 30 + n_pose
+    net, sd, assets = make_net(C, seed, precision=precision, n_pose=n_pose)
+    assert sd["left_mano_regressor.mano_regressor.4.weight"].shape == (16 + n_pose, 1024)
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits, n_pose=n_pose)
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    torch.cuda.synchronize()
+    assert out["left"]["hand_pose"].shape == (B, n_pose) and out["right"]["betas"].shape == (B, 10)
+    check_against(out, net, ref, trace, B, N)
+    rows = torch.zeros(B, evdist.packed_width(N, n_pose), device="cuda")
+    net.net.fps_init = inits
+    with torch.no_grad():
+        net.net(xyz.cuda(), net.hands, rows=rows)
+    got = evdist.unpack_outputs(rows, N, n_pose)
+    for side in ("left", "right"):
+        for k in ("global_orient", "hand_pose", "betas", "transl", "vertices", "j3d"):
+            assert torch.equal(got[side][k], out[side][k]), (side, k)
+    # a hand model with another number of components than the checkpoint regresses is refused, by name
+    from ev2hands_amd.mano import create_mano_layers
+    wrong = create_mano_layers(None, "cuda:0", 6 if n_pose != 6 else 7, assets=assets)
+    net.net.fps_init = inits
+    with pytest.raises(Exception, match="pose coefficients"):
+        net.net(xyz.cuda(), wrong)

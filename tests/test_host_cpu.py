@@ -35,7 +35,7 @@ def test_struct_layouts_and_abi_version(built):
     built.ev2h_struct_sizes(sizes)
     mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc, _lib.TensorDesc)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 6 == _lib.ABI_VERSION
+    assert built.ev2h_abi_version() == 7 == _lib.ABI_VERSION
 
 
 def test_workspace_size_grows_linearly(built):

@@ -25,6 +25,7 @@ def test_oracle_matches_reference_fixture(path):
     g = np.load(path)
     B, C, N, seed = [int(v) for v in g["meta"]]
     kind = str(g["kind"])
+    n_pose = int(g["n_pose"]) if "n_pose" in g.files else synth.MANO_CMPS        # TEHNet(n_pose_params): head width 3 + n_pose + 13
     xyz = synth.synth_cloud(kind, B, C, N, seed)
     assert np.array_equal(xyz.numpy(), g["xyz"]), "synthetic input generator drifted"
     inits = synth.fps_inits(B, N, seed)
@@ -34,8 +35,8 @@ def test_oracle_matches_reference_fixture(path):
         assert str(g["ckpt"]) == "trained"
         sd = trained_ckpt.trained_state_dict(C)
     else:
-        sd = synth.synth_state_dict(C, seed)
-    hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed))
+        sd = synth.synth_state_dict(C, seed, n_pose)
+    hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed), ncomps=n_pose)
     if "tie_eps" in g.files:       # near-tie segmentation head (oracle/stress.py)
         from oracle import stress
         sd = stress.near_tie_state_dict(sd, xyz, inits, hands, float(g["tie_eps"]))
@@ -43,7 +44,7 @@ def test_oracle_matches_reference_fixture(path):
     mhlnes = bool(int(g["mhlnes"])) if "mhlnes" in g.files else False
     xin = xyz.clone()
     with torch.no_grad():
-        out = tehnet_oracle.tehnet_forward(sd, xin, hands, fps_init=inits, trace=trace, mhlnes=mhlnes)
+        out = tehnet_oracle.tehnet_forward(sd, xin, hands, fps_init=inits, trace=trace, mhlnes=mhlnes, n_pose=n_pose)
     if mhlnes:       # TEHNet.py:176-177 overwrites channel 2 of the caller's tensor; the fixture holds what the reference left behind
         assert np.array_equal(xin.numpy(), g["xyz_after"]) and not np.array_equal(xin.numpy(), g["xyz"])
     else:
