@@ -174,14 +174,15 @@ struct BallArgs {
     int nchunk;     // workgroups per window = ceil(S / cpw); the grid is 1-D: nchunk * B workgroups
 };
 
-constexpr int BALL_CTR_PER_WG = 32, BALL_UNR = 4;
+constexpr int BALL_CTR_PER_WG = 4, BALL_UNR = 4;      // one centroid per wave
 
-// LDS_PTS = false (N > 8192: the window does not fit LDS): the points are read from global memory (L2-resident, coalesced)
-template <bool LDS_PTS>
+// The window's points are read through L2 (coalesced 1 KiB per wave and step), never staged in LDS: a scan is a chain of dependent
+// round trips with a data-dependent early exit, and what hides it is many short waves, not a copy of the points per workgroup.
+// Round 4 moved the windows above 2048 points to this form (the 128 KB copy of an 8192-point window left one workgroup per CU: 3x);
+// round 5 (XCD-aware grid, one centroid per wave) measured it ahead at 2048 points as well (+0.4 .. 1 % of the step, same-box
+// builds, profiles/r5_ab_ball_l2_n2048.txt), so the LDS form is gone.
 __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restrict__ pts4, const float4* __restrict__ ctr4,
                                                          int N, int S, BallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float4* spts = reinterpret_cast<float4*>(smem_raw);
     // XCD-aware 1-D grid: the dispatcher deals workgroups to the 8 XCDs round-robin; xcd_remap gives every XCD a CONTIGUOUS range
     // of (window, chunk) pairs, so that the workgroups that scan one window's points sit on one XCD and find them in its L2.
     // (A [chunk, window] 2-D grid spread every window over all 8 L2s: at 128 windows of 8192 points each L2 saw all 16.8 MB of
@@ -190,11 +191,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
     const int b = L / a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* src = pts4 + (size_t)b * N;
-    if constexpr (LDS_PTS) {
-        for (int p = tid; p < N; p += 256) spts[p] = src[p];
-        __syncthreads();
-    }
-
+    (void)tid;
     const int s_begin = (L - b * a.nchunk) * a.cpw;
     for (int s = s_begin + wave; s < s_begin + a.cpw && s < S; s += 4) {
         const float4 c = ctr4[(size_t)b * S + s];
@@ -210,7 +207,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
 #pragma unroll
             for (int u = 0; u < BALL_UNR; ++u) {
                 const int p = base + 64 * u + lane;
-                const float4 q = LDS_PTS ? spts[p < N ? p : N - 1] : src[p < N ? p : N - 1];
+                const float4 q = src[p < N ? p : N - 1];
                 // square_distance (pointnet2_utils.py:37-39): -2*(c.q) + |c|^2 + |q|^2, dot as an fma chain
                 const float dot = __fmaf_rn(c.z, q.z, __fmaf_rn(c.y, q.y, __fmul_rn(c.x, q.x)));
                 d[u] = __fadd_rn(__fadd_rn(__fmul_rn(-2.f, dot), c.w), q.w);
@@ -416,27 +413,9 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
         a.gidx[i] = gidx[i];
     }
     a.cnt = cnt;
-    // 32 centroids per workgroup amortise the staging of the window's points; a launch that would leave CUs idle (a few windows at a
-    // time: 16 workgroups for enc.sa1 at B = 1) takes fewer per workgroup instead -- same per-centroid arithmetic, same results
     a.cpw = BALL_CTR_PER_WG;
-    while (a.cpw > 4 && (long)ceil_div(S, a.cpw) * B < 256) a.cpw >>= 1;
-    // the L2 form (below) stages nothing, so a workgroup costs nothing to start: one centroid per wave -- a scan is a chain of
-    // dependent L2 round trips with a data-dependent early exit, and many short waves hide both the latency and the imbalance
-    // (16 windows of 8192 points, enc.sa1: 266 -> see DESIGN.md section 11; 32 centroids per workgroup left 8 scans in a row per wave)
-    constexpr int BALL_LDS_MAX = 2048;      // windows up to the reference's operating point are staged in LDS (measured neutral there)
-    const bool l2_form = N > BALL_LDS_MAX;
-    if (l2_form) a.cpw = 4;
     a.nchunk = ceil_div(S, a.cpw);
-    dim3 grid((unsigned)a.nchunk * (unsigned)B);
-    // Windows above BALL_LDS_MAX points are read through L2 instead of an LDS copy: at N = 8192 the 128 KB of staged points leave ONE
-    // 4-wave workgroup per CU and the scan is latency-bound (round 4: 3x faster, config 5's shape +14.6 %).  Same arithmetic, same results.
-    if (l2_form) {
-        ball_query_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
-        EV2H_CHECK_LAUNCH();
-        return EV2H_OK;
-    }
-    ball_query_kernel<true><<<grid, 256, (size_t)N * sizeof(float4), (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4,
-                                                                                             N, S, a);
+    ball_query_kernel<<<dim3((unsigned)a.nchunk * (unsigned)B), 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
