@@ -94,9 +94,10 @@ struct SaBCfg {
     // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
     // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
     static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 16;
-    // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, one 64-bit (window, max) key in the
-    // resident one -- see the kernel's epilogue
-    static constexpr int REC = (NS == 2) ? 64 : 0;
+    // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, REC_SLOTS per-window running maxima
+    // in the resident one -- see the kernel's epilogue
+    static constexpr int REC_SLOTS = 64;
+    static constexpr int REC = (NS == 2) ? REC_SLOTS * 4 : 0;
     static constexpr int SMALL_NOREC = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
     static constexpr int SMALL = SMALL_NOREC + REC;
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 
     int buf = 0;
     if constexpr (RES && NS == 2) {
-        if (tid == 0) *reinterpret_cast<unsigned long long*>(smem + WBYTES + Cfg::SMALL_NOREC) = 0ull;      // (window, max) key of the record combine
+        if (tid < Cfg::REC_SLOTS) reinterpret_cast<unsigned*>(smem + WBYTES + Cfg::SMALL_NOREC)[tid] = 0u;      // per-window running maxima of the record combine
     }
     if constexpr (RES) {
         dma_tile(p.W2s, smem, NC1 * Cfg::TB2);
@@ -949,17 +950,21 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         // windows, tools/debug/sa_small_grid.py).  The waves of a workgroup work on consecutive groups -- almost always one
         // window -- so their maxima are combined in LDS first:
         //  * streamed variants (the waves already meet at barriers): one atomic per (workgroup, window);
-        //  * resident variant (barrier-free persistent waves): a 64-bit LDS key (window, max) filters the updates -- a wave only
-        //    goes to memory when it raises its workgroup's running maximum of the window (windows ascend along a wave's walk).
+        //  * resident variant (barrier-free persistent waves, which drift apart -- also across a window boundary): one LDS slot per
+        //    window of this workgroup's XCD range holds the workgroup's running maximum of that window; a wave only goes to memory
+        //    when it raises it.  (A single (window, max) key dropped the update of a lagging wave once a leading wave had moved
+        //    on to the next window -- an under-estimated record, caught by the sharded-equals-unsharded test.)  Windows beyond
+        //    the slots (more than 64 windows per XCD) update memory directly.
         // max is exact, associative and idempotent: the record is the same number whatever the route.
         if (p.out_amax) {
             am = wave_max_u32_dpp(am);
             char* rec = smem + WBYTES + Cfg::SMALL_NOREC;
             if constexpr (RES) {
                 if (lane == 0 && am) {
-                    const unsigned long long key = ((unsigned long long)(unsigned)b << 32) | am;
-                    const unsigned long long old = atomicMax(reinterpret_cast<unsigned long long*>(rec), key);
-                    if (key > old) atomicMax(&p.out_amax[b], am);
+                    const int slot = b - (xcd * p.per_xcd) / p.S;          // windows of this XCD's group range, in order
+                    unsigned old = 0u;
+                    if (slot >= 0 && slot < Cfg::REC_SLOTS) old = atomicMax(reinterpret_cast<unsigned*>(rec) + slot, am);
+                    if (am > old) atomicMax(&p.out_amax[b], am);
                 }
             } else {
                 int* sb = reinterpret_cast<int*>(rec);
