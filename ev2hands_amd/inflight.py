@@ -5,7 +5,7 @@ latency-bound for a fifth of its time: farthest point sampling is 512 DEPENDENT 
 windows there are), followed by selection kernels that are chains of L2 round trips.  Consecutive batches are independent
 (eval-mode windows share nothing, /root/reference/src/Ev2Hands/model/TEHNet.py:168-197), so the head of batch i + 1 can run
 under the matrix-pipe-bound tail of batch i: `InflightForward` issues forward i on stream i mod depth with its own workspace.
-16 windows of 8192 points: 7 090 -> 8 560 windows/s with depth 2 (profiles/r5_inflight_n8192.txt); at 128 windows per GPU the
+16 windows of 8192 points: 7 090 -> 8 560 windows/s with depth 2 (profiles/r5_inflight.txt); at 128 windows per GPU the
 chip is already full (+2.5 %), at the headline shape (256 windows of 2048 points) it is neutral -- the default is one in flight.
 
 Numbers are unchanged by construction: the same ev2h_forward with the same arguments, only on another stream

@@ -248,3 +248,83 @@ def tehnet_forward(sd, xyz_in, mano_hands, fps_init=None, n_pose=6, training=Fal
             d["faces"] = np.tile(mano_hands[side].faces, (xyz_in.shape[0], 1, 1))
         out[side] = d
     return out
+
+
+# --------------------------------------------------------------------------- the same function in float64
+def tehnet_forward_f64(sd, xyz_in, mano_hands64, selections, n_pose=6):
+    """The network FUNCTION of tehnet_forward evaluated in float64 on the SAME discrete selections: `selections` is the trace of a
+    float32 tehnet_forward of the same input (FPS indices, ball-query groups, 3-NN indices and weights -- the reference computes
+    those from float32 coordinates, and they define which function is evaluated), every feature contraction, BatchNorm, softmax and
+    the MANO layer (`mano_hands64` = mano_oracle.make_hands(..., dtype=torch.float64)) run in float64.  Not a parity oracle: a
+    yardstick -- how far the reference's OWN float32 sums are from the exact value of its function, next to which the arithmetic
+    modes of the library are read (tests/trained_truth_report.py).  Relative coordinates are formed in float32 first, as the
+    reference forms them (pointnet2_utils.py:245), then widened."""
+    t = selections
+    sd = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+    def msg(prefix, xyz_cm, feat_cm, npoint, nb):
+        xyz = xyz_cm.permute(0, 2, 1).contiguous()
+        feat = feat_cm.permute(0, 2, 1).contiguous().double()
+        B = xyz.shape[0]
+        ctr = gather_points(xyz, t[prefix + ".fps"])
+        outs = []
+        for i in range(nb):
+            gi = t[f"{prefix}.group{i}"]
+            gx = gather_points(xyz, gi)
+            gx = gx - ctr.view(B, npoint, 1, 3)
+            g = torch.cat([gather_points(feat, gi), gx.double()], dim=-1).permute(0, 3, 2, 1).contiguous()
+            j = 0
+            while f"{prefix}.conv_blocks.{i}.{j}.weight" in sd:
+                g = _conv_bn_relu_2d(g, sd, f"{prefix}.conv_blocks.{i}.{j}", f"{prefix}.bn_blocks.{i}.{j}")
+                j += 1
+            outs.append(g.max(2)[0])
+        return ctr.permute(0, 2, 1).contiguous(), torch.cat(outs, dim=1)
+
+    def group_all(prefix, xyz_cm, feat_cm):
+        xyz = xyz_cm.permute(0, 2, 1).contiguous().double()
+        feat = feat_cm.permute(0, 2, 1).contiguous()
+        B, N, _ = xyz.shape
+        g = torch.cat([xyz.view(B, 1, N, 3), feat.view(B, 1, N, -1)], dim=-1).permute(0, 3, 2, 1).contiguous()
+        k = 0
+        while f"{prefix}.mlp_convs.{k}.weight" in sd:
+            g = _conv_bn_relu_2d(g, sd, f"{prefix}.mlp_convs.{k}", f"{prefix}.mlp_bns.{k}")
+            k += 1
+        return g.max(2)[0]
+
+    def fp(prefix, N, S, feat1_cm, feat2_cm):
+        f2 = feat2_cm.permute(0, 2, 1).contiguous()
+        B = f2.shape[0]
+        if S == 1:
+            interp = f2.repeat(1, N, 1)
+        else:
+            interp = (gather_points(f2, t[prefix + ".nn_idx"]) * t[prefix + ".nn_w"].double().view(B, N, 3, 1)).sum(dim=2)
+        x = torch.cat([feat1_cm.permute(0, 2, 1).contiguous(), interp], dim=-1) if feat1_cm is not None else interp
+        x = x.permute(0, 2, 1).contiguous()
+        k = 0
+        while f"{prefix}.mlp_convs.{k}.weight" in sd:
+            x = _conv_bn_relu_1d(x, sd, f"{prefix}.mlp_convs.{k}", f"{prefix}.mlp_bns.{k}")
+            k += 1
+        return x
+
+    B, _, N = xyz_in.shape
+    xyz0 = xyz_in[:, :3, :]
+    l1_xyz, l1 = msg("sa1", xyz0, xyz_in, 512, 3)
+    l2_xyz, l2 = msg("sa2", l1_xyz, l1, 128, 2)
+    l3 = group_all("sa3", l2_xyz, l2)
+    l2 = fp("fp3", 128, 1, l2, l3)
+    l1 = fp("fp2", 512, 128, l1, l2)
+    l0 = fp("fp1", N, 512, None, l1)
+    seg = classifier(sd, l0)
+    out = {"class_logits": seg, "l0": l0}
+    for side in ("left", "right"):
+        hf = attention(seg, l0, query_conv(sd, side, l0))
+        p = f"{side}_mano_regressor"
+        m_xyz, m1 = msg(p + ".sa1", xyz0, hf, 128, 2)
+        h = group_all(p + ".sa2", m_xyz, m1).squeeze(-1)
+        h = F.relu(F.linear(h, sd[p + ".mano_regressor.0.weight"], sd[p + ".mano_regressor.0.bias"]))
+        h = _bn(h, sd, p + ".mano_regressor.2")
+        prm = F.linear(h, sd[p + ".mano_regressor.4.weight"], sd[p + ".mano_regressor.4.bias"])
+        args = {"global_orient": prm[:, :3], "hand_pose": prm[:, 3:3 + n_pose], "betas": prm[:, 3 + n_pose:-3], "transl": prm[:, -3:]}
+        res = mano_hands64[side](**args)
+        out[side] = {"vertices": res.vertices, "j3d": res.joints, "params": prm, "hand_features": hf, **args}
+    return out

@@ -324,7 +324,7 @@ def test_trained_checkpoint_under_the_stress_transforms(transform):
     units: fold scale 1 / sqrt(eps) = 316, profiles/r5_trained_checkpoint_report.txt).  A unit whose pre-activation sits within
     rounding of zero is amplified 316-fold by ANY change of summation order, so two correct fp32 evaluations of this network
     differ by up to ~1e-4 on unlucky windows (this window, no transform: exact-fp32 MFMA 1.9e-5, bf16x3 1.1e-4, f16x2 2.5e-6
-    against the CPU oracle, left-hand parameters; tools/debug/trained_stress_probe.py) -- the reference-run fixtures, where all
+    against the CPU oracle, left-hand parameters; tests/trained_stress_probe.py) -- the reference-run fixtures, where all
     modes sit at <= 2.2e-5, are the parity gate (test_gpu_forward.py).  Here: argmax and every selection identical, every mode
     inside 5e-4, and the HEADLINE mode no worse than the two unconditional ones (f16x2 <= 4 x max(f32, bf16x3) + 1e-5)."""
     _need_gpu()

@@ -1,6 +1,6 @@
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from ev2hands_amd import synth
 from ev2hands_amd.model import TEHNetWrapper
