@@ -6,7 +6,12 @@ activations) and FPS starts, runs the forward in exact fp32 and in f16x2 (and bf
   * every float output within 2e-5 relative of the exact-fp32 mode,
   * segmentation argmax identical wherever the fp32 top-2 margin exceeds 2e-5 of the logit scale,
   * a second run of the same case bit-identical (determinism).
-usage: python tests/fuzz_modes.py [ncases] [seed]          prints one line per case and a summary; exit code 1 on any violation."""
+usage: python tests/fuzz_modes.py [ncases] [seed]          prints one line per case and a summary; exit code 1 on any violation.
+FUZZ_TRAINED=1: the checkpoints are the ones that came out of the reference's training loop (tests/trained_ckpt.py), plain or under
+the function-preserving transforms; the float bar is then 2e-4 (two correct fp32-class evaluations of that network differ by ~1.5e-5
+typically and by up to ~1e-4 on a window that puts a dead unit's pre-activation within rounding of zero), hot
+pixels are left out (they drive the trained regressors to pose angles of thousands of radians, where the MANO layer is ill-defined in
+every arithmetic), and the summary prints the distribution."""
 import os
 import sys
 
@@ -44,6 +49,11 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     bad = 0
     worst = 0.0
+    trained = bool(os.environ.get("FUZZ_TRAINED"))
+    tol = 2e-4 if trained else 2e-5
+    all_worst = []
+    if trained:
+        import trained_ckpt
     for case in range(ncases):
         C = int(rng.choice([4, 5]))
         kind = str(rng.choice(["E", "E", "U", "L"]))
@@ -62,7 +72,9 @@ def main():
         p1, p2 = float(rng.random()), float(rng.random())         # drawn for every case, so that FUZZ_ONLY replays a case exactly
         if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != case:
             continue
-        sd = synth.synth_state_dict(C, seed)
+        sd = trained_ckpt.trained_state_dict(C) if trained else synth.synth_state_dict(C, seed)
+        if trained and variant == "heavy":
+            variant = "plain"                                # (re-drawing the weights' magnitudes would un-train them)
         if variant == "channels":
             sd = sc.rescale_channels(sd, [3, 8, 14][int(p1 * 3)], seed, include_l0=p2 < 0.5)
         elif variant == "dead":
@@ -81,7 +93,7 @@ def main():
         # (not with MHLNES=1: z := mean event count would put the coordinates hundreds of units outside the normalised cube, where
         #  the reference's matmul-form distances are cancellation noise -- 0.06 absolute at |z| ~ 700 against radii of 0.1 .. 0.8 --
         #  and its own result is ill-defined)
-        inp = ["plain", "plain", "hot", "counts"][int(p2 * 4)] if (C == 5 and not mh) else "plain"
+        inp = ["plain", "plain", "hot", "counts"][int(p2 * 4)] if (C == 5 and not mh and not trained) else "plain"
         if inp == "hot":                                     # a hot pixel: 1e2 .. 1e6 events in one point per window
             xyz = sc.add_outlier_points(xyz, 10.0 ** (2 + 4 * p1), channel=3, per_window=1, seed=seed)
         elif inp == "counts":                                # all event counts 100 x larger
@@ -100,7 +112,7 @@ def main():
                 o = tehnet_oracle.tehnet_forward(sd, xyz.cpu().clone(), hands, fps_init=inits, mhlnes=bool(mh))
             otr = {"class_logits": o["class_logits"], **{f"{s_}.{k}": o[s_][k] for s_ in ("left", "right") for k in KEYS}}
             e = {k: rel(ref[k], otr[k]) for k in ref}
-            if max(e.values()) > 1e-4:
+            if max(e.values()) > (5e-4 if trained else 1e-4):
                 k = max(e, key=e.get)
                 msgs.append(f"f32 vs CPU oracle: {k} rel err {e[k]:.2e}")
             if not torch.equal(ref["class_logits"].argmax(1).cpu(), otr["class_logits"].argmax(1)):
@@ -132,7 +144,7 @@ def main():
                 print(f"   {prec} vs f32 mode      :", {k: f"{v:.1e}" for k, v in errs.items()})
             worst = max(worst, max(errs.values()))
             case_worst = max(case_worst, max(errs.values()))
-            if max(errs.values()) > 2e-5:
+            if max(errs.values()) > tol:
                 k = max(errs, key=errs.get)
                 msgs.append(f"{prec}: {k} rel err {errs[k]:.2e}")
             lg = ref["class_logits"].double().cpu()
@@ -147,8 +159,12 @@ def main():
                 msgs.append(f"{prec}: non-finite output")
         print(f"case {case:3d}: C={C} {kind} B={B} N={N:5d} mhlnes={mh} ckpt={variant:22s} seed={seed:6d}  {case_worst:.1e}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
         bad += bool(msgs)
+        all_worst.append(case_worst)
         del net
     print(f"{ncases} cases, {bad} with violations, worst relative difference to the exact-fp32 mode {worst:.2e}")
+    if all_worst:
+        q = np.quantile(np.array(all_worst), [0.5, 0.9, 0.99])
+        print(f"per-case worst difference: median {q[0]:.1e}, 90th percentile {q[1]:.1e}, 99th {q[2]:.1e}" + ("  (trained checkpoints)" if trained else ""))
     return 1 if bad else 0
 
 
