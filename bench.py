@@ -592,7 +592,16 @@ def run_rank(a) -> int:
         L.ev2h_set_side_stream(prev)
         timed(2)
         gains = [round(v, 4) for v in all_ranks(off_local / on_local)]
+        try:
+            from ev2hands_amd import _lib as _evlib
+            probe = _evlib.side_stream_probe(50)
+        except Exception:  # noqa: BLE001 -- EV2H_TWO_STREAMS=0: nothing to probe
+            probe = 0.0
+        probes = [round(v, 3) for v in all_ranks(probe)]
         selfcheck = {"two_stream_gain": round(t_off / t_on, 4), "two_stream_gain_per_rank": gains, "steps_each": k,
+                     "side_stream_probe_per_rank": probes,
+                     "side_stream_probe_note": "ev2h_side_stream_probe: a 50 us spin kernel on each of the two streams at once / one alone; ~1.0 = the "
+                                               "streams run concurrently, ~2.0 = they share a hardware queue (0 = side stream off)",
                      "note": "wall time of k steps with ev2h_set_side_stream(0) / with the default two-stream schedule; ~1.00 on a rank "
                              "means its side stream shares a hardware queue with the main stream"}
         if pipe is not None:

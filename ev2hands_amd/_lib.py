@@ -98,7 +98,7 @@ class Outputs(C.Structure):
 
 
 EXPORTS = [
-    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_struct_sizes",
+    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_side_stream_probe", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.ev2h_struct_sizes.restype = None
     L.ev2h_struct_sizes.argtypes = [C.c_size_t * 8]
     L.ev2h_set_side_stream.argtypes = [ci]
+    L.ev2h_side_stream_probe.argtypes = [vp, ci, C.POINTER(C.c_float)]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -212,3 +213,14 @@ def ptr(t) -> int:
 def stream_handle() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def side_stream_probe(spin_us: int = 50) -> float:
+    """ev2h_side_stream_probe on the current device and stream: (time of one spin kernel on each of the caller's stream and the
+    library's side stream at once) / (time of one alone).  ~1.0: the two streams run concurrently; ~2.0: they share a hardware
+    queue and the forward's overlaps are lost (create the wrapper / call ev2h_init() before other code creates streams,
+    INTEGRATION.md section 3).  Raises if the side stream is switched off."""
+    r = C.c_float(0.0)
+    check(lib().ev2h_side_stream_probe(stream_handle(), int(spin_us), C.byref(r)), "ev2h_side_stream_probe")
+    return float(r.value)
+

@@ -126,6 +126,56 @@ static SideCtx* side_ctx() {     // the current device's side stream, or nullptr
     return c.state == 1 ? &c : nullptr;
 }
 
+// ---------------------------------------------------------------------------------------- side-stream probe
+namespace {
+// spins for ~ticks of the constant-rate real-time counter (100 MHz on gfx950) without touching memory
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long r0 = wall_clock64();
+    while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio) {
+    EV2H_CHECK_ARG(ratio && spin_us > 0 && spin_us <= 100000);
+    *ratio = 0.f;
+    SideCtx* side = side_ctx();
+    if (!side || g_side_disabled) {
+        ev2h_set_error("ev2h_side_stream_probe: the side stream is switched off");
+        return EV2H_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e[4];
+    for (auto& x : e) EV2H_CHECK_HIP(hipEventCreate(&x));
+    int rate_khz = 100000, dev = 0;                         // wall_clock64 ticks per millisecond
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    const unsigned long long ticks = (unsigned long long)rate_khz * (unsigned long long)spin_us / 1000ull;
+    auto cleanup = [&]() { for (auto& x : e) (void)hipEventDestroy(x); };
+    float one = 0.f, two = 0.f;
+    hipError_t err = hipSuccess;
+    for (int rep = 0; rep < 2 && err == hipSuccess; ++rep) {   // (first repetition: code load)
+        err = hipEventRecord(e[0], st);
+        spin_kernel<<<1, 64, 0, st>>>(ticks);
+        if (err == hipSuccess) err = hipEventRecord(e[1], st);
+        // the pair: fork exactly as ev2h_forward does
+        if (err == hipSuccess) err = hipEventRecord(side->ev[4], st);
+        if (err == hipSuccess) err = hipStreamWaitEvent(side->stream, side->ev[4], 0);
+        if (err == hipSuccess) err = hipEventRecord(e[2], st);
+        spin_kernel<<<1, 64, 0, st>>>(ticks);
+        spin_kernel<<<1, 64, 0, side->stream>>>(ticks);
+        if (err == hipSuccess) err = hipEventRecord(side->ev[3], side->stream);
+        if (err == hipSuccess) err = hipStreamWaitEvent(st, side->ev[3], 0);
+        if (err == hipSuccess) err = hipEventRecord(e[3], st);
+        if (err == hipSuccess) err = hipStreamSynchronize(st);
+    }
+    if (err == hipSuccess) err = hipEventElapsedTime(&one, e[0], e[1]);
+    if (err == hipSuccess) err = hipEventElapsedTime(&two, e[2], e[3]);
+    cleanup();
+    if (err != hipSuccess) { ev2h_set_error("ev2h_side_stream_probe: %s", hipGetErrorString(err)); return EV2H_ERR_HIP; }
+    *ratio = one > 0.f ? two / one : 0.f;
+    return EV2H_OK;
+}
+
 // ---------------------------------------------------------------------------------------- small kernels
 // internal entry points of other translation units (not part of the C ABI)
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d);

@@ -82,6 +82,13 @@ int ev2h_init(void);
  * what the overlaps buy in its own process (bench.py's `two_stream_gain`): a gain of ~1.00 where ~1.05 is expected means the side
  * stream shares a hardware queue with the caller's stream (see ev2h_init). */
 int ev2h_set_side_stream(int enabled);
+/* Does the library's side stream really run CONCURRENTLY with `stream` in this process?  (HIP multiplexes streams onto a few
+ * hardware queues; two streams that share one run in order, without any error -- see ev2h_init.)  Launches one short spin kernel
+ * (~spin_us microseconds of s_sleep, no memory traffic) on `stream` alone, then one on each of the two streams at once, timed by
+ * events; *ratio = (time of the pair) / (time of one): ~1.0 = concurrent, ~2.0 = the two streams are serialised.  Synchronises
+ * `stream` (a start-up probe, ~0.2 ms); not capturable.  Returns EV2H_ERR_ARG when the side stream is switched off
+ * (EV2H_TWO_STREAMS=0 / creation failed): then there is nothing to probe and *ratio is set to 0.  [ABI 7] */
+int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio);
 /* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp, tensor_desc]. */
 void ev2h_struct_sizes(size_t out[8]);
 

@@ -214,3 +214,21 @@ def test_default_auto_mode_keeps_f16x2_on_the_trained_checkpoints(C, kind, monke
         want = ref(xyz)
     assert torch.equal(out["class_logits"], want["class_logits"]) and torch.equal(out["left"]["vertices"], want["left"]["vertices"])
     assert torch.equal(out["right"]["j3d"], want["right"]["j3d"])
+
+
+def test_side_stream_probe_sees_two_concurrent_streams():
+    """ev2h_side_stream_probe: the library's side stream must really run next to the caller's (HIP maps streams onto a few hardware
+    queues; a shared queue serialises them silently and the forward loses ~5 %).  In a fresh process that created the wrapper first
+    the pair of spin kernels takes about as long as one; with the side stream switched off the probe refuses."""
+    _need_gpu()
+    from ev2hands_amd import _lib
+    net, sd, assets = make_net(4, 1, precision="f16x2")          # creates the side stream (ev2h_init)
+    r = [_lib.side_stream_probe(50) for _ in range(3)]
+    print("side-stream probe (pair / single):", [f"{v:.2f}" for v in r])
+    assert 0.8 < min(r) < 1.5, r
+    prev = _lib.lib().ev2h_set_side_stream(0)
+    try:
+        with pytest.raises(_lib.Ev2hError):
+            _lib.side_stream_probe(50)
+    finally:
+        _lib.lib().ev2h_set_side_stream(prev)
