@@ -1,3 +1,8 @@
+#!/bin/bash
+# Everything measured for the round, on ONE box (run through gpurun from the repo root; outputs under gpurun_out/, the summaries that
+# are committed are copied to profiles/):  the float64 truth report and the precision report on the trained checkpoints, the whole GPU
+# suite, the bench lines, the rocprofv3 kernel tables / PMC traffic / SQ counters for N = 2048 and N = 8192, the batch sweep at 8192
+# points, forwards in flight.
 python tests/trained_truth_report.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_trained_truth_report.txt
 python -m pytest tests -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/r5_gpu_tests.txt
 bash tools/bench_lines.sh r5 > gpurun_out/r5_bench_lines_summary.txt 2>&1
