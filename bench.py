@@ -490,10 +490,14 @@ def run_rank(a) -> int:
                 out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
             return out
 
-        def forward(rows=None):
+        def forward(rows=None, then=None):
             net.net.fps_init = inits
             if infl is not None:                       # K forwards in flight: returns a ticket, the work is on stream i mod K
-                return infl.submit(xyz, rows=rows, post=collision_terms)
+                def post(out):
+                    collision_terms(out)
+                    if then is not None:               # e.g. the asynchronous all-gather of this step, issued behind the forward on ITS stream
+                        then()
+                return infl.submit(xyz, rows=rows, post=post)
             with torch.no_grad():
                 return collision_terms(net.net(xyz, net.hands, rows=rows))
 
@@ -510,10 +514,15 @@ def run_rank(a) -> int:
         rows = pipe.rows()
         if a.stub:
             rows.copy_(evdist.pack_outputs(forward()))
+        elif infl is not None:
+            # forwards in flight AND a gather: the collective is issued from the slot's stream right behind its forward (RCCL orders
+            # a collective after the stream it is called on), so that the caller's stream never waits for a forward and the next
+            # submit() is not held back
+            box = []
+            forward(rows, then=lambda: box.append(pipe.submit()))
+            return box[0].result() if sync_gather else box[0]
         else:
-            t = forward(rows)
-        if infl is not None:
-            t.result()                                 # the gather is issued on the caller's stream: it waits for that forward
+            forward(rows)
         pending = pipe.submit()
         return pending.result() if sync_gather else pending
 
