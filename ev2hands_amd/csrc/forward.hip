@@ -144,8 +144,14 @@ extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* 
         return EV2H_ERR_ARG;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e[4];
-    for (auto& x : e) EV2H_CHECK_HIP(hipEventCreate(&x));
+    hipEvent_t e[4] = {};
+    for (auto& x : e) {
+        if (hipEventCreate(&x) != hipSuccess) {
+            for (auto& y : e) if (y) (void)hipEventDestroy(y);
+            ev2h_set_error("ev2h_side_stream_probe: hipEventCreate failed");
+            return EV2H_ERR_HIP;
+        }
+    }
     int rate_khz = 100000, dev = 0;                         // wall_clock64 ticks per millisecond
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
@@ -390,8 +396,8 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
             d.out_amax = out_amax;
             d.w1x_norm = br.w1x_norm; d.dmax = (float)br.radius * 1.0000002f /* rounded up: a bound */; d.w2_norm = br.w2_norm; d.b2_max = br.b2_max;
         }
-        d.cnt = cnt ? cnt + i : nullptr; d.cnt_ld = m.nbranch;
-        if (i == 0 && xyz_out) { d.xyz_out = xyz_out; d.xyz_ld = xyz_ld; }      // the consumer's raw-xyz columns: written once, by the first branch      // padding-only strips are skipped (bit-identical: test_sa_mlp_max_padding_skip)
+        d.cnt = cnt ? cnt + i : nullptr; d.cnt_ld = m.nbranch;      // padding-only strips are skipped (bit-identical: test_sa_mlp_max_skips_padding_strips)
+        if (i == 0 && xyz_out) { d.xyz_out = xyz_out; d.xyz_ld = xyz_ld; }      // the consumer's raw-xyz columns: written once, by the first branch
         char t[40];
         snprintf(t, sizeof(t), "%s.%d", tag, i);
         prof_begin(t, st);
