@@ -89,6 +89,25 @@ def _rank(rank, world, port, gB, N, C, precision, q):
             res["last_gather_equals_unsharded"] = bool(ok)
             pipe.drain()
 
+            # the same with two forwards in flight per rank (ev2hands_amd/inflight.py; config 5 as 16-window shards): forward i on
+            # stream i mod 2 with its own workspace, the gather of step i issued from that stream right behind its forward
+            from ev2hands_amd.inflight import InflightForward
+            infl = InflightForward(net, depth=2)
+            pend2 = []
+            for step in range(4):
+                net.net.fps_init = evdist.shard_fps_inits(inits, lo, hi)
+                box = []
+                infl.submit(xyz[lo:hi], rows=pipe.rows(), post=lambda out: box.append(pipe.submit()))
+                pend2.append(box[0])
+            infl.drain()
+            got = pend2[3].result()
+            ok = torch.equal(got["class_logits"], want["class_logits"])
+            for side in ("left", "right"):
+                for k in want[side]:
+                    ok = ok and torch.equal(got[side][k], want[side][k])
+            res["inflight_gather_equals_unsharded"] = bool(ok)
+            pipe.drain()
+
             # the per-rank two-stream self-check of bench.py, with both ranks hammering the same GPU
             L = _lib.lib()
 
@@ -154,5 +173,6 @@ def test_two_ranks_on_one_gpu_gather_equals_unsharded(gB, N, C, precision):
         assert out[r]["gathered_equals_unsharded"], out
         assert out[r]["last_gather_equals_unsharded"], out
         assert out[r]["generation_guard"], out
+        assert out[r]["inflight_gather_equals_unsharded"], out
         assert out[r]["single_stream_rows_equal_two_stream_rows"], out
         assert 0.3 < out[r]["two_stream_gain"] < 3.0, out          # a report (two processes share the GPU here), not a bar
