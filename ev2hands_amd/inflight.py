@@ -58,7 +58,10 @@ class InflightForward:
         k = self.i % self.depth
         self.i += 1
         if self.ws[k] is None or self.ws[k].numel() < nbytes:
-            self.ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            # allocated ON the slot's stream: a workspace that is outgrown while its last forward is still running goes back to
+            # that stream's pool, where any reuse is ordered behind that forward (the caching allocator's own rule)
+            with torch.cuda.stream(self.streams[k]):
+                self.ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self.streams[k], self.ws[k]
 
     def submit(self, xyz: torch.Tensor, rows=None, post=None) -> "InflightForward.Ticket":
