@@ -14,6 +14,11 @@ Training signal (the datasets and the MANO assets are absent; the point is the o
   * per hand the 22 regressed parameters -> smooth functions of that blob's centre; MSE on them and on the 21 joints the
     (differentiable) MANO restatement makes of them (the reference's loss also mixes parameter and joint terms).
 
+Schedule: 480 steps of 4 windows x 2048 points, C = 4 (steps 0-319: cross entropy x 1, joint term x 100 -- the joint error of a
+random start is huge; steps 320-479: cross entropy x 3, joint term x 10, so that the segmentation head gets its share of the
+gradient: CE 2.4 -> 1.3, accuracy 0.30 -> 0.58), checkpointed every 20 steps in /tmp so that a run can be resumed; then 48 steps
+for the C = 5 variant.  About 35 minutes on 8 CPU threads.
+
 Outputs:
   tests/golden/trained_weights_c4.npz   fp16 deltas on synth_state_dict(4, 100) + BN statistics (tests/trained_ckpt.py)
   tests/golden/trained_weights_c5.npz   the C = 5 checkpoint's differing entries (enc.sa1 first convolutions re-trained)
