@@ -78,6 +78,10 @@ def parse(argv=None):
                     help="forwards in flight (ev2hands_amd/inflight.py: step i on stream i mod K with its own workspace); for shards too small to fill "
                          "the chip, e.g. --points 8192 --batch 16 --inflight 2.  Default 1: one forward at a time on one stream")
     ap.add_argument("--cloud", default="E", choices=["U", "E"])
+    ap.add_argument("--weights", default="random", choices=["random", "trained"],
+                    help="random: hash-generated random-init checkpoint (the contract's default); trained: the checkpoint that came out of the "
+                         "reference's training loop (tests/trained_ckpt.py) -- same shapes and FLOPs, other bit patterns (dead units, saturated "
+                         "softmax): an extra line for profiles/, never the default")
     ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f16x2"), choices=["f32", "bf16x3", "f16x2", "bf16"],
                     help="arithmetic of the MFMA contractions: f16x2 = fp32-class 2-plane fp16 split with per-window range scaling "
                          "(default), bf16x3 = fp32-class 3-plane bf16 split -- both pass the 1e-4 / exact-argmax parity bar, also on "
@@ -255,7 +259,7 @@ def live_pmc_traffic(a, timeout_s=300):
         raise RuntimeError("rocprofv3 not found")
     nsteps = 3
     child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site", "--no-host-io",
-             "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud]
+             "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud, "--weights", a.weights]
     tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
     env["TMPDIR"] = "/tmp"
@@ -460,6 +464,10 @@ def run_rank(a) -> int:
         else:
             assets = {s: synth.synth_mano_assets(s, 0) for s in ("left", "right")}
         sd = synth.synth_state_dict(Cc, 0)
+        if a.weights == "trained":
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import trained_ckpt
+            sd = trained_ckpt.trained_state_dict(Cc)
         net = TEHNetWrapper(dev, mano_assets=assets)
         net.load_state_dict(sd, strict=True)
         net.eval()
@@ -733,7 +741,9 @@ def run_rank(a) -> int:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "stub" if a.stub else DTYPE[a.precision], "data": "synthetic",
             "config": {"workload": f"TEHNet.forward+MANO both hands, B={B}/GPU N={N} C={Cc} fp32, {a.cloud}-clouds, "
-                                   f"random-init 342-key checkpoint, synthetic MANO-shaped assets"
+                                   + ("random-init 342-key checkpoint" if a.weights == "random" else
+                                      "342-key checkpoint out of the reference's training loop on synthetic clouds (tests/trained_ckpt.py)")
+                                   + ", synthetic MANO-shaped assets"
                                    + (" + intersection-loss term per window (pair search cap 16, list sized 2 x 1538 x 16: never truncated; conic "
                                       "distance-field penalty)" + (" + collision count for the score (second search, cap 8)" if a.collision_score else "") +
                                       "; hand meshes: " +
