@@ -170,6 +170,8 @@ __global__ __launch_bounds__(1024) void attn_simfold_kernel(const float* __restr
 
 // one wave per point: lanes hold 4 channels each of the 256-wide value row, both hands' sim in registers
 constexpr int CTX_PTS_PER_WAVE = 32;
+// VBF16: the value rows are bf16 (the BF16 mode stores l0 that way, forward.hip); ldv counts values either way
+template <bool VBF16>
 __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restrict__ sim, const float* __restrict__ value,
                                                            int ldv, int N, size_t rows_total, float* __restrict__ hf8,
                                                            unsigned* __restrict__ amax, int amax_hand_stride,
@@ -191,7 +193,13 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
     unsigned am = 0u;
     for (int n = n0; n < n0 + CTX_PTS_PER_WAVE && n < N; ++n) {
         const size_t row = (size_t)b * N + n;
-        const float4 v = *reinterpret_cast<const float4*>(value + row * ldv + lane * 4);
+        float4 v;
+        if constexpr (VBF16) {
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(value) + row * ldv + lane * 4);
+            v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+        } else {
+            v = *reinterpret_cast<const float4*>(value + row * ldv + lane * 4);
+        }
         float acc[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -275,7 +283,16 @@ extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ld
                                  int amax_hand_stride, const float* value_unscale, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
     dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
-    attn_context_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride, value_unscale);
+    attn_context_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride, value_unscale);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+// internal (forward.hip, BF16 mode): the same with bf16 value rows
+int ev2h_attn_context_bf16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, const float* value_unscale, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
+    dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
+    attn_context_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(sim, reinterpret_cast<const float*>(value_pm), ldv, N, (size_t)B * N, hf8, nullptr, 0, value_unscale);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -185,7 +185,9 @@ extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* 
 // ---------------------------------------------------------------------------------------- small kernels
 // internal entry points of other translation units (not part of the C ABI)
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d);
-int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, ev2h_stream_t stream);
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream);
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream);
+int ev2h_attn_context_bf16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, const float* value_unscale, ev2h_stream_t stream);
 int ev2h_attn_simfold_partials(const float* zpart, int rows_per_partial, const float* logits_pm, int B, int N, const float* w4t_left,
                                const float* w4t_right, const float* b4_left, const float* b4_right, float* sim, ev2h_stream_t stream);
 
@@ -647,6 +649,26 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     RUN(dense(w->fp2[0], ws.f("l1cat"), 576, B * 512, ws.f("fp2h"), 256, 1, st, rg(R_L1A, 512, R_FP2H, 512, R_L1B)));
     RUN(dense(w->fp2[1], ws.f("fp2h"), 256, B * 512, ws.f("l1new"), 128, 1, st, rg(R_FP2H, 512, R_L1NEW, 512)));
     // ---- fp1 (TEHNet.py:186): 3-NN 512 -> N, no skip
+    // [r5] BF16: l0 -- the forward's one N-row, 256-wide tensor: written once (fp1), read three times (segmentation head, k = 3 query
+    // convolution, attention context) -- is stored as bf16 when all four run in their fused forms.  Every BF16 reader rounds it to
+    // bf16 before multiplying anyway (the context read it in fp32: it now sees the rounded values, inside the mode's own error).
+    // 2.1 of the BF16 step's 6.0 GB of HBM traffic touch l0.  EV2H_L0_F32=1: A/B switch (fp32 l0 in BF16 as well).
+    static const bool unfused_cls = getenv("EV2H_CLS_UNFUSED") != nullptr;      // A/B switch
+    static const bool unfused_zsum = getenv("EV2H_ATTN_UNFUSED_ZSUM") != nullptr;
+    static const bool l0_f32 = getenv("EV2H_L0_F32") != nullptr;
+    const bool cls_fused = prec != EV2H_PREC_F32 && w->clsm.W2s && !unfused_cls;
+    ev2h_gemm_desc qd{};                     // the first query convolution (both hands in one GEMM), used further down
+    {
+        const Rng r0 = rg(R_L0, N);
+        qd.x_amax = r0.xa; qd.x_amax2 = r0.xa2; qd.x_group_rows = r0.xg;
+        qd.X = ws.f("l0"); qd.ldx = 256; qd.W = w->qconv0.W; qd.ldw = w->qconv0.ldw;
+        qd.M = R; qd.N = w->qconv0.O; qd.K = w->qconv0.K;
+        qd.bias = w->qconv0.b; qd.relu = 1; qd.post_scale = w->qconv0.post_scale; qd.post_shift = w->qconv0.post_shift;
+        qd.taps = 3; qd.rows_per_seq = N; qd.precision = prec; qd.Ws = w->qconv0.Ws; qd.ws_tile_rows = w->qconv0.ws_tile_rows;
+        qd.w_unscale = w->qconv0.w_unscale;
+    }
+    const bool zsum_ok = !unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws && ev2h_gemm_bf16_zsum_supported(&qd);
+    const bool l0_bf16 = prec == EV2H_PREC_BF16 && fp1_fused && cls_fused && zsum_ok && !l0_f32;
     if (fp1_fused) {
         // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
         // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
@@ -663,7 +685,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
             d.t_scale = ws.p1scale(4); d.t_amax = ws.r(R_FP1T); d.w2_norm = m.br[0].w2_norm; d.b2_max = m.br[0].b2_max; d.out_amax = ws.r(R_L0);
         }
         prof_begin("fp1", st);
-        RUN(ev2h_fp_mlp(&d, st));
+        RUN(ev2h_fp_mlp_ex(&d, 0, l0_bf16, st));
         prof_end("fp1", st);
     } else {
         RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
@@ -678,8 +700,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         EV2H_CHECK_HIP(hipEventRecord(side->ev[6], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[6], 0));
     }
-    static const bool unfused_cls = getenv("EV2H_CLS_UNFUSED") != nullptr;      // A/B switch
-    if (prec != EV2H_PREC_F32 && w->clsm.W2s && !unfused_cls) {
+    if (cls_fused) {
         // 16-bit modes: both layers in one row-chain kernel -- the 256-wide hidden layer (537 MB at B = 256) never reaches memory,
         // and the logits are written point-major (for the attention) and channel-major (the output) by the same kernel
         const ev2h_sa_branch& c = w->clsm;
@@ -689,7 +710,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits; d.out_cm_stride = out->logits_stride;
         d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec;
         if (ws.ranges_on) { d.t_amax = ws.r(R_L0); d.w2_norm = c.w2_norm; d.b2_max = c.b2_max; }
-        RUN(ev2h_fp_mlp(&d, sx));
+        RUN(ev2h_fp_mlp_ex(&d, l0_bf16, 0, sx));
     } else {
         RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
         RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
@@ -701,26 +722,15 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     // [r4] BF16 / F16X2: q1 is NOT WRITTEN -- the GEMM's epilogue forms the attention's key-weighted sums of its own tile
     // (gemm_bf16.hip: zsum_epilogue), which makes the logits its input: the classifier is waited for first.
     // EV2H_ATTN_UNFUSED_ZSUM=1: A/B switch (q1 to memory, attn_zsum_kernel reads it back).
-    static const bool unfused_zsum = getenv("EV2H_ATTN_UNFUSED_ZSUM") != nullptr;
     bool zsum_fused = false;
-    if (!unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws) {
-        const Rng r0 = rg(R_L0, N);
-        ev2h_gemm_desc d{};
-        d.x_amax = r0.xa; d.x_amax2 = r0.xa2; d.x_group_rows = r0.xg;
-        d.X = ws.f("l0"); d.ldx = 256; d.W = w->qconv0.W; d.ldw = w->qconv0.ldw;
-        d.M = R; d.N = w->qconv0.O; d.K = w->qconv0.K;
-        d.bias = w->qconv0.b; d.relu = 1; d.post_scale = w->qconv0.post_scale; d.post_shift = w->qconv0.post_shift;
-        d.taps = 3; d.rows_per_seq = N; d.precision = prec; d.Ws = w->qconv0.Ws; d.ws_tile_rows = w->qconv0.ws_tile_rows;
-        d.w_unscale = w->qconv0.w_unscale;
-        // the shape preconditions (N % 128 == 0, ...) are tested BEFORE the launch site is bracketed: one event pair per step, and
-        // a genuine error of the fused launch is returned, never turned into the two-pass schedule
-        if (ev2h_gemm_bf16_zsum_supported(&d)) {
-            if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));          // logits ready
-            prof_begin("qconv0", st);
-            RUN(ev2h_gemm_bf16_zsum(&d, ws.f("logits_pm"), ws.f("zpart"), st));
-            prof_end("qconv0", st);
-            zsum_fused = true;
-        }
+    if (zsum_ok) {
+        // the shape preconditions (N % 128 == 0, ...) were tested above (zsum_ok), BEFORE the launch site is bracketed: one event pair
+        // per step, and a genuine error of the fused launch is returned, never turned into the two-pass schedule
+        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));          // logits ready
+        prof_begin("qconv0", st);
+        RUN(ev2h_gemm_bf16_zsum(&qd, ws.f("logits_pm"), ws.f("zpart"), l0_bf16, st));
+        prof_end("qconv0", st);
+        zsum_fused = true;
     }
     if (!zsum_fused) {
         prof_begin("qconv0", st);
@@ -738,7 +748,8 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         RUN(ev2h_attn_sim_folded(ws.f("logits_pm"), ws.f("q1"), 512, B, N, w->qconv4T[0], w->qconv4T[1], w->qconv4[0].b, w->qconv4[1].b,
                                  ws.f("zpart"), ws.f("sim"), st));
     }
-    RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, w->l0_unscale, st));
+    if (l0_bf16) RUN(ev2h_attn_context_bf16rows(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), w->l0_unscale, st));
+    else RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, w->l0_unscale, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
     if (fork) {
         EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[1], 0));       // ball queries done

@@ -37,6 +37,7 @@ struct GemmBP {
     // TAP3 occupancy kernel only: the attention's key-weighted column sums (attention.hip: Z[c][t][i]) formed in the epilogue instead of
     // storing Y -- zs_key = logits, point-major [M][4]; zs_out = chunk partials [M / 128][12][N] (see zsum_epilogue)
     const float4* zs_key; float* zs_out;
+    int x_bf16;             // TAP3 kernel, NS = 1 only (internal): X holds bf16 values (ldx counts values) -- the rows ARE the operand plane
 };
 
 template <int NS>
@@ -647,15 +648,22 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         oka = ok;
     };
     // TAP3: chunk kc of the centre rows (LDS rows 1..128) and, threads 0..3, of the two halo rows (LDS rows 0 and 129)
+    // x_bf16 (NS = 1): 16 bf16 values = 32 bytes = the first two registers of ra / rh
+    auto load16h = [&](const unsigned short* g, f32x4 (&r)[4]) {
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(r[0]), "=&v"(r[1]) : "v"(g) : "memory");
+    };
     auto gload3 = [&](int kc) {
         const int k = kc * GB_BK + lseg * 16;
         const int m = m0 + lrow;
         oka = m < p.M;
-        load16(p.X + (oka ? (long)m : 0) * p.ldx + k, true, ra);            // TAP3: Kc % 32 == 0
+        const bool xh = (NS == 1) && p.x_bf16;
+        if (xh) load16h(reinterpret_cast<const unsigned short*>(p.X) + (oka ? (long)m : 0) * p.ldx + k, ra);
+        else load16(p.X + (oka ? (long)m : 0) * p.ldx + k, true, ra);            // TAP3: Kc % 32 == 0
         if (tid < 4) {
             const long mh = (tid >> 1) ? (long)m0 + GB_BM : (long)m0 - 1;
             okh = (tid >> 1) ? ((m0 + GB_BM) % p.rows_per_seq != 0 && mh < p.M) : (m0 % p.rows_per_seq != 0);
-            load16(p.X + (okh ? mh : 0) * p.ldx + k, true, rh);
+            if (xh) load16h(reinterpret_cast<const unsigned short*>(p.X) + (okh ? mh : 0) * p.ldx + k, rh);
+            else load16(p.X + (okh ? mh : 0) * p.ldx + k, true, rh);
         }
     };
     auto wait_all = [&]() {
@@ -665,6 +673,17 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
     };
     auto swrite_row = [&](const f32x4 (&r)[4], bool ok, int ldsrow, float sc) {
+        if constexpr (NS == 1 && TAP3) {
+            if (p.x_bf16) {               // the loaded 32 bytes are the plane: two 16-byte pieces of this row's k half
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    u32x4 v = __builtin_bit_cast(u32x4, r[hh]);
+                    if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+                    *reinterpret_cast<u32x4*>(sA + ldsrow * RS + lseg * 32 + hh * 16) = v;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             f32x4 r0 = r[2 * hh], r1 = r[2 * hh + 1];
@@ -978,8 +997,9 @@ bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d) {
     return true;
 }
 
-int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, ev2h_stream_t stream) {
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d && key_pm && zpart && ev2h_gemm_bf16_zsum_supported(d));
+    EV2H_CHECK_ARG(!x_bf16 || d->precision == EV2H_PREC_BF16);
     GemmBP p{};
     p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = nullptr; p.ldy = 0;
     p.M = d->M; p.N = d->N; p.taps = 3; p.Kc = d->K; p.K = d->K * 3;
@@ -991,6 +1011,7 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
         p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
     }
     p.zs_key = reinterpret_cast<const float4*>(key_pm); p.zs_out = zpart;
+    p.x_bf16 = x_bf16;
     p.tiles_n = d->N / GO_BN;
     p.nblk = (d->M / GB_BM) * p.tiles_n;
     if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true>(p, (const char*)d->Ws, (hipStream_t)stream);

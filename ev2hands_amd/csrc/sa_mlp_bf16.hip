@@ -63,6 +63,10 @@ struct SaBP {
     // One window at a time (demo.py:24-33) has 16 workgroups for 256 CUs in the 128-centroid modules: 88 -> ~25 us per launch.
     int spg;
     float* xyz_out; int xyz_ld;            // optional: the group's centroid as 8 more columns of the consumer's input rows (ev2h_sa_desc)
+    // BF16 row chains only (internal, ev2h_fp_mlp_ex): the input rows of MODE 2 / the output rows are bf16 (2 bytes per value; ldp /
+    // ldo still count VALUES) -- l0, the one N-row 256-wide tensor of the forward, is written once and read three times, and
+    // every reader of the BF16 mode rounds it to bf16 before it multiplies anyway
+    int t_bf16, out_bf16;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -400,7 +404,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int j = 0; j < ((ROWS && !DIRECT) ? 3 : 1); ++j)
 #pragma unroll
-                for (int j4 = 0; j4 < 4; ++j4) trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + qi(j4));
+                for (int j4 = 0; j4 < 4; ++j4) {
+                    if constexpr (NS == 1 && DIRECT) {
+                        if (p.t_bf16) {          // 4 bf16 values = 8 bytes at value offset 32 c + 4 qi(j4) of this lane's row
+                            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(trow[j]) + (size_t)(c * 32 + 4 * qi(j4)) * 2);
+                            trw[j][j4] = f32x4{__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                                               __uint_as_float(h.y & 0xffff0000u)};
+                            continue;
+                        }
+                    }
+                    trw[j][j4] = *reinterpret_cast<const f32x4*>(trow[j] + c * 8 + qi(j4));
+                }
         };
         auto blend = [&]() {
 #pragma unroll
@@ -411,7 +425,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                                         : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
         if constexpr (DIRECT) {
-            trow[0] = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp);
+            trow[0] = (NS == 1 && p.t_bf16)
+                          ? reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.P1) + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp * 2)
+                          : reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp);
             fetch(0);
             blend();
         } else if constexpr (ROWS) {
@@ -882,6 +898,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         float o = acc[r] * c3 + b3u;
                         if (p.relu_out) o = fmaxf(o, 0.f);
                         if (colok && row0 + 4 * half + pt < p.N) {
+                            if (NS == 1 && p.out_bf16) {
+                                unsigned short* o16 = reinterpret_cast<unsigned short*>(p.out) + ((size_t)b * p.N + row0 + 4 * half + pt) * p.ldo + 32 * u + l31;
+                                *o16 = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{o, 0.f}, bf16x2)) & 0xffffu);
+                            } else
                             orow[(size_t)pt * p.ldo] = o;
                             if (ocm) ocm[pt] = o;
                             am = max(am, abs_bits(o));
@@ -1102,8 +1122,13 @@ extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10
     return ev2h_gemm_tile_geometry(planes, out + 6);
 }
 
-extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream);
+extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) { return ev2h_fp_mlp_ex(d, 0, 0, stream); }
+
+// internal (forward.hip): t_bf16 -- the input rows of form (b) are bf16; out_bf16 -- the output rows are written as bf16.  BF16 mode only.
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(d && d->T && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
+    EV2H_CHECK_ARG(!(t_bf16 || out_bf16) || (d->precision == EV2H_PREC_BF16 && (!out_bf16 || !d->out_cm) && (!t_bf16 || !d->nn_idx)));
     EV2H_CHECK_ARG((d->nn_idx != nullptr) == (d->nn_w != nullptr));
     EV2H_CHECK_ARG(d->B > 0 && d->N > 0 && d->ldt >= d->C1 && (d->ldt % 4) == 0);
     const int ncols = d->out_cols > 0 ? d->out_cols : d->C3;
@@ -1114,6 +1139,7 @@ extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) {
     p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
     p.ncols = ncols; p.relu_out = d->no_relu_out ? 0 : 1; p.out_cm = d->out_cm;
+    p.t_bf16 = t_bf16; p.out_bf16 = out_bf16;
     p.out_cm_stride = d->out_cm_stride ? d->out_cm_stride : (size_t)ncols * d->N;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * p.S, SAB_WAVES);

@@ -664,7 +664,7 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
 # re-associates sums (the un-fused forms), selections and argmax identical in every case.
 AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_SA_STREAMED", "1", True), ("EV2H_GEMM_NO_TAP3", "1", True),
                ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFUSED_ZSUM", "1", False),
-               ("EV2H_L1_TABLE", "1", False)]
+               ("EV2H_L1_TABLE", "1", False), ("EV2H_L0_F32", "1", True)]       # (EV2H_L0_F32 acts in BF16 only: see test_bf16_l0_storage below)
 
 
 _AB_SCRIPT = """
@@ -844,3 +844,32 @@ def test_forward_with_other_pose_widths(n_pose, C, precision):
     net.net.fps_init = inits
     with pytest.raises(Exception, match="pose coefficients"):
         net.net(xyz.cuda(), wrong)
+
+
+def test_bf16_l0_storage_agrees_with_fp32_storage(tmp_path):
+    """[r5] BF16 stores l0 -- written once by the fp1 chain, read by the segmentation head, the k = 3 query convolution and the
+    attention context -- as bf16 (2.1 of the step's 6.0 GB of HBM traffic touch it).  Every BF16 reader rounds it to bf16 anyway, so
+    against EV2H_L0_F32=1 (fp32 storage, the round-4 form): identical selections, IDENTICAL logits (the head sees the same bf16
+    values either way), the regressed outputs within bf16 rounding of each other (only the attention context used to read the
+    unrounded values)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    text = _AB_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    text = text.replace("('f16x2', 'bf16x3')", "('bf16',)").replace("1100", "1024")
+    script.write_text(text)
+    env0 = {k: v for k, v in os.environ.items() if k != "EV2H_L0_F32"}
+    res = {}
+    for tag, env in (("bf16_l0", {}), ("f32_l0", {"EV2H_L0_F32": "1"})):
+        out = tmp_path / f"{tag}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(env0, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)["bf16"]
+    a, b = res["bf16_l0"], res["f32_l0"]
+    for k in ("gidx", "nn"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["logits"], b["logits"])
+    worst = max(rel(a[k], b[k]) for k in a if k not in ("gidx", "nn"))
+    print(f"bf16: l0 stored as bf16 vs fp32: worst relative difference {worst:.2e}")
+    assert 0.0 < worst < 3e-2
