@@ -667,7 +667,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         qd.taps = 3; qd.rows_per_seq = N; qd.precision = prec; qd.Ws = w->qconv0.Ws; qd.ws_tile_rows = w->qconv0.ws_tile_rows;
         qd.w_unscale = w->qconv0.w_unscale;
     }
-    const bool zsum_ok = !unfused_zsum && (prec == EV2H_PREC_BF16 || prec == EV2H_PREC_F16X2) && w->qconv0.Ws && ev2h_gemm_bf16_zsum_supported(&qd);
+    const bool zsum_ok = !unfused_zsum && prec != EV2H_PREC_F32 && w->qconv0.Ws && ev2h_gemm_bf16_zsum_supported(&qd);
     const bool l0_bf16 = prec == EV2H_PREC_BF16 && fp1_fused && cls_fused && zsum_ok && !l0_f32;
     if (fp1_fused) {
         // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
@@ -719,7 +719,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[7], side->stream));
     // ---- query convolutions (TEHNet.py:191-192), both hands' first conv in one GEMM
     // (q1's range record is only needed by the unfolded second convolution: the folded form reads q1 in fp32)
-    // [r4] BF16 / F16X2: q1 is NOT WRITTEN -- the GEMM's epilogue forms the attention's key-weighted sums of its own tile
+    // [r4; BF16X3: r5] every plane mode: q1 is NOT WRITTEN -- the GEMM's epilogue forms the attention's key-weighted sums of its own tile
     // (gemm_bf16.hip: zsum_epilogue), which makes the logits its input: the classifier is waited for first.
     // EV2H_ATTN_UNFUSED_ZSUM=1: A/B switch (q1 to memory, attn_zsum_kernel reads it back).
     bool zsum_fused = false;

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         }
     }
 
-    if constexpr (TAP3 && NS <= 2) {          // (BF16X3 keeps the two-pass form: its instantiation would spill)
+    if constexpr (TAP3) {             // (NS = 3: two registers of the epilogue's straight-line code go to scratch; the tap loop has none)
         if (p.zs_out) { zsum_epilogue<NS>(p, acc, m0, wm, wn, n0, smem, tid); return; }
     }
     gemm_epilogue<NS, 2, 2, false>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
@@ -987,7 +987,7 @@ int ev2h_gemm_tile_geometry(int ns, int out[2]) {
 // ev2h_gemm_bf16_zsum_supported: the shapes the tap kernel takes -- the caller tests them FIRST and runs the two-pass form otherwise;
 // an error of the launch itself is then an error, not a silent change of schedule.
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d) {
-    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_BF16) &&
+    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_BF16X3) &&
           d->K % GB_BK == 0 && d->rows_per_seq > 0 && d->rows_per_seq % GB_BM == 0 && d->M % d->rows_per_seq == 0 && d->N % GO_BN == 0))
         return false;
     if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
@@ -1016,6 +1016,7 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     p.nblk = (d->M / GB_BM) * p.tiles_n;
     if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true>(p, (const char*)d->Ws, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_BF16) return launch_go_t<1, true>(p, (const char*)d->Ws, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16X3) return launch_go_t<3, true>(p, (const char*)d->Ws, (hipStream_t)stream);
     return EV2H_ERR_ARG;
 }
 

@@ -746,7 +746,7 @@ def test_bf16_table_switch_agrees_with_the_table_free_layer1(tmp_path):
 
 
 def test_query_convolution_without_q1_agrees_with_the_two_pass_form(tmp_path):
-    """[r4] bf16 / f16x2 at window sizes that tile by 128 rows: the first query convolution forms the attention's key-weighted sums in its
+    """[r4, bf16x3: r5] bf16 / f16x2 / bf16x3 at window sizes that tile by 128 rows: the first query convolution forms the attention's key-weighted sums in its
     epilogue and never writes q1 (gemm_bf16.hip: zsum_epilogue).  EV2H_ATTN_UNFUSED_ZSUM=1 = q1 to memory + attn_zsum_kernel (the
     fp32 fma chain): same selections, f16x2 within 1e-5 of each other (different summation order), bf16 within its own rounding;
     both inside the parity bar against the oracle (test_forward_matches_oracle runs the default at N = 256 .. 2048)."""
@@ -755,7 +755,7 @@ def test_query_convolution_without_q1_agrees_with_the_two_pass_form(tmp_path):
     import sys
     script = tmp_path / "run.py"
     text = _AB_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    text = text.replace("('f16x2', 'bf16x3')", "('f16x2', 'bf16')").replace("1100", "1024")
+    text = text.replace("('f16x2', 'bf16x3')", "('f16x2', 'bf16', 'bf16x3')").replace("1100", "1024")
     assert "1024" in text
     script.write_text(text)
     env0 = {k: v for k, v in os.environ.items() if k != "EV2H_ATTN_UNFUSED_ZSUM"}
@@ -765,7 +765,7 @@ def test_query_convolution_without_q1_agrees_with_the_two_pass_form(tmp_path):
         r = subprocess.run([sys.executable, str(script), str(out)], env=dict(env0, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = torch.load(out)
-    for prec, tol in (("f16x2", 1e-5), ("bf16", 3e-2)):
+    for prec, tol in (("f16x2", 1e-5), ("bf16", 3e-2), ("bf16x3", 1e-5)):
         a, b = res["fused"][prec], res["two_pass"][prec]
         for k in ("gidx", "nn"):
             assert torch.equal(a[k], b[k]), (prec, k)
