@@ -364,12 +364,12 @@ static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, i
     return ev2h_gemm(&g, st);
 }
 
-// BF16 with raw feature rows (kf == 8: enc.sa1, the regressors' sa1): layer 1 runs on the matrix pipe inside the fused kernel straight
-// from the feature rows (ev2h_sa_desc.feat) -- no layer-1 table is computed, written (1.46 GB per 256-window step) or gathered.
-// EV2H_L1_TABLE=1: A/B switch back to the table (the path BF16X3 and F32 always take).
+// Plane modes with raw feature rows (kf == 8: enc.sa1, the regressors' sa1): layer 1 runs on the matrix pipe inside the fused kernel
+// straight from the feature rows (ev2h_sa_desc.feat) -- no layer-1 table is computed, written (1.46 GB per 256-window step) or
+// gathered.  (BF16, F16X2: round 4; BF16X3: round 5.)  EV2H_L1_TABLE=1: A/B switch back to the table (the path F32 always takes).
 static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
     static const bool table = getenv("EV2H_L1_TABLE") != nullptr;
-    return (precision == EV2H_PREC_BF16 || precision == EV2H_PREC_F16X2) && m.kf == 8 && !table;
+    return precision != EV2H_PREC_F32 && m.kf == 8 && !table;
 }
 
 static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,

@@ -6,10 +6,10 @@
 //           fp32 -- dropped terms are O(2^-24), i.e. fp32-class accuracy at 6/16 of the fp32 MFMA cost;
 //   NS = 1  plain bf16 operands (round to nearest even), fp32 accumulate -- BASELINE.json config 3.
 // All biases, ReLUs and the max stay in fp32.  Layer 1 has three forms (see L1M / L1F / the VALU path in the kernel):
-//   * gathered layer-1 table row + exact fp32 relative-xyz fma chain (every mode when the features are a real table: enc.sa2;
-//     BF16X3 always);
+//   * gathered layer-1 table row + exact fp32 relative-xyz fma chain (every mode when the features are a real table: enc.sa2);
 //   * BF16: one MFMA per 32-channel chunk (inputs as two bf16 planes), on top of the table row or -- raw feature rows -- instead of it;
-//   * F16X2 with raw feature rows: two MFMAs per chunk with per-neighbour power-of-two factors for the feature and xyz groups.
+//   * F16X2 with raw feature rows: two MFMAs per chunk with per-neighbour power-of-two factors for the feature and xyz groups;
+//   * BF16X3 with raw feature rows [r5]: three MFMAs per chunk = the six plane products, no factors (bf16 keeps the float's exponent).
 // Other round-4 additions: fragment reads issued a group ahead (FRAG_PIPE), the next strip's gather requested during the current
 // strip (XPF), a group's strips spread over the waves of a workgroup when the grid is smaller than the chip (SaBP::spg).
 //
@@ -97,7 +97,8 @@ struct SaBCfg {
     static constexpr int SB2W = (NS == 2) ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
     // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
     // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
-    static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 16;
+    // BF16X3: three A tiles per channel row ([w0 | w0], [w1 | w1], [w2 | w0]: 96 B) + the b1 bias
+    static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 96 + C1 * 4;
     // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, REC_SLOTS per-window running maxima
     // in the resident one -- see the kernel's epilogue
     static constexpr int REC_SLOTS = 64;
@@ -139,7 +140,11 @@ struct SaBCfg {
 template <int C1, int C2, int C3, int NS, bool RES, int MODE = 0>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
     constexpr int WV = SAB_WAVES;
-    constexpr bool ROWS = MODE != 0, DIRECT = MODE == 2;
+    // MODE = 3 (BF16X3 only): the set abstraction with RAW FEATURE ROWS compiled in (L1F below) -- in BF16 / F16X2 the table and the
+    //              feature form share one kernel and choose at run time; the three-plane kernels have no registers left for both
+    //              (the 128-196-256 instantiation spilled 92 bytes), so each form is its own instantiation there.
+    constexpr bool ROWS = MODE == 1 || MODE == 2, DIRECT = MODE == 2;
+    static_assert(MODE != 3 || NS == 3, "MODE 3 is the BF16X3 feature-row form");
     static_assert(!(RES && ROWS), "the row-output variants stream their tiles");
     // BF16, set abstraction: LAYER 1 ON THE MATRIX PIPE.  D1[channel][neighbour] = A1 [32 channels][16 k] x B1 [16 k][32 neighbours]
     // (+ C = the gathered table row when the features are a table) with the k slots
@@ -162,7 +167,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // s1 H1 = relu(D1 (s1 / kappa_j) + s1 b1).  A neighbour's inputs are scaled by its OWN maxima -- a 1e7-event hot pixel no longer
     // sets the scale of the other neighbours, which is what the exact fp32 layer 1 used to guarantee -- no layer-1 table is
     // computed, stored or gathered (48 B instead of 512 B per neighbour), and one fma replaces three.
-    constexpr bool L1F = (NS == 2) && !ROWS;
+    // BF16X3 with raw feature rows [r5]: the same without any factor.  B1f = [x0(8) | x1(8)], B1g = [x0 | x2] (x = x0 + x1 + x2, the exact
+    // three-plane split), A = [w2 | w0] (x B1g), [w1 | w1], [w0 | w0] (x B1f): three MFMAs = the six products of Planes<3>, small terms
+    // first, on top of C = b1.
+    constexpr bool L1F = !ROWS && (NS == 2 || (NS == 3 && MODE == 3));
     // L2PIPE / H2FUSE (round 4, late): conversion work of one wave placed between its MFMA groups (see the layer-2 loop and the first
     // layer-3 step).  Same-box step A/B (profiles/r4_ab_h2fuse_l2pipe.txt): BF16 +1.3 % with H2FUSE, +1.9 % with both; F16X2 +1.1 % with
     // H2FUSE, and L2PIPE costs it 0.5 % (its widest instantiation then spills 24 bytes) -- so F16X2 keeps the un-pipelined layer 2.
@@ -197,8 +205,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int half = lane >> 5, l31 = lane & 31;
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
-    const bool fmode = L1F && p.feat != nullptr;               // (uniform)
-    float* sb1w = reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1;      // F16X2 feature mode: s1 b1 of this wave's window
+    const bool fmode = (NS == 3) ? (MODE == 3) : (L1F && p.feat != nullptr);               // (uniform; BF16X3: a compile-time constant)
+    // F16X2 feature mode: s1 b1 of this wave's window; BF16X3 feature mode: b1 (one copy)
+    float* sb1w = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * 96);
 
     if constexpr (L1M) {
         // A1 [C1][16 k] bf16 (one 32-byte row per channel), k slots as listed above
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     } else if constexpr (!ROWS) {
         if (fmode) {
             // A tiles of layer 1: row i = [wh(v0..v7) | wh(v0..v7)] then [wl(v0..v7) | 0], v = (f0..f4, dx, dy, dz), planes of W1f / uf, W1x / ux
-            const float iu = 1.f / p.u1f, iux = 1.f / p.u1x;      // (powers of two: exact)
+            const float iu = (NS == 2) ? 1.f / p.u1f : 1.f, iux = (NS == 2) ? 1.f / p.u1x : 1.f;      // (powers of two: exact; BF16X3: no plane factor)
             for (int i = tid; i < C1; i += WV * 64) {
                 const float4 w = p.W1x[i];
                 float k[8];
@@ -229,12 +238,23 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 for (int j = 0; j < 8; ++j) k[j] = 0.f;
                 for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iu;
                 k[5] = w.x * iux; k[6] = w.y * iux; k[7] = w.z * iux;
-                unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
+                if constexpr (NS == 2) {
+                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned o[NS > 1 ? NS : 2];
-                    if constexpr (NS == 2) split_planes<2>(k[2 * j], k[2 * j + 1], o);
-                    d[j] = o[0]; d[4 + j] = o[0]; d[8 + j] = o[1]; d[12 + j] = 0u;
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned o[2];
+                        split_planes<2>(k[2 * j], k[2 * j + 1], o);
+                        d[j] = o[0]; d[4 + j] = o[0]; d[8 + j] = o[1]; d[12 + j] = 0u;
+                    }
+                } else if constexpr (NS == 3) {
+                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 24;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned o[3];
+                        split_planes<3>(k[2 * j], k[2 * j + 1], o);
+                        d[j] = o[0]; d[4 + j] = o[0]; d[8 + j] = o[1]; d[12 + j] = o[1]; d[16 + j] = o[2]; d[20 + j] = o[0];
+                    }
+                    sb1w[i] = p.b1[i];
                 }
             }
         } else {
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         const float4* trow[3] = {nullptr, nullptr, nullptr};       // ROWS: the three table rows of this lane's point ...
         float tw[3] = {0.f, 0.f, 0.f};                             // ... and their inverse-distance weights
         u32x4 b1f = {0u, 0u, 0u, 0u};                      // L1M / L1F: the B operand of the layer-1 MFMA
+        u32x4 b1g = {0u, 0u, 0u, 0u};                      // L1F, BF16X3: the second one ([x0 | x2])
         float cj = 1.f;                                    // L1F: s1 / kappa_j of this lane's neighbour
         // ROWS: raw = (w0 T0 + w1 T1) + w2 T2 of chunk c (pointnet2_utils.py:303 applied to the layer-1 table; the table is stored
         // scaled by s1 in F16X2, so the blend is s1 H1 before the ReLU)
@@ -446,7 +467,20 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             dx = __fsub_rn(q.x, ctr.x); dy = __fsub_rn(q.y, ctr.y); dz = __fsub_rn(q.z, ctr.z);
             if constexpr (NS == 2) { if (!fmode) { dx *= s1; dy *= s1; dz *= s1; } }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
             if (fmode) {
-                if constexpr (L1F) {
+                if constexpr (L1F && NS == 3) {
+                    // (no XPF in this mode: the feature row is requested here)  B1f = [x0 | x1], B1g = [x0 | x2] of v = (f0..f4, dx, dy, dz)
+                    const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx) * p.ldf);
+                    const float4 fa = fr[0], fb = fr[1];
+                    const float v[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, dx, dy, dz};
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        unsigned o[3];
+                        split_planes<3>(v[2 * w], v[2 * w + 1], o);
+                        b1f[w] = half ? o[1] : o[0];
+                        b1g[w] = half ? o[2] : o[0];
+                    }
+                }
+                if constexpr (L1F && NS == 2) {
                     // B1 = [xh(v0..v7) | xl(v0..v7)], v = (f0..f4, dx, dy, dz) of this lane's neighbour times its own power of two s_j
                     float v[8] = {f0_cur.x, f0_cur.y, f0_cur.z, f0_cur.w, f1_cur.x, dx, dy, dz};
                     const float af = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fabsf(v[4]));
@@ -500,7 +534,20 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         // products with [wl | 0] and [wh | wh]
         auto layer1 = [&](int c) {
             f32x16 acc;
-            if constexpr (L1F) {
+            if constexpr (L1F && NS == 3) {
+                // C = b1: D register 4q + e of a lane is channel 32c + 8q + 4 half + e
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[e];
+                }
+                const char* ar = smem + WBYTES + (32 * c + l31) * 96 + half * 16;
+                const u32x4 a0 = *reinterpret_cast<const u32x4*>(ar), a1 = *reinterpret_cast<const u32x4*>(ar + 32), a2 = *reinterpret_cast<const u32x4*>(ar + 64);
+                acc = mfma_planes<3>(a2, b1g, acc);
+                acc = mfma_planes<3>(a1, b1f, acc);
+                return mfma_planes<3>(a0, b1f, acc);
+            } else if constexpr (L1F) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
                 const char* ar = smem + WBYTES + (32 * c + l31) * 64 + half * 16;
@@ -557,7 +604,19 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     bp[w >> 2][0][w & 3] = relu_pk_bf16(o[0]);
                 }
             } else if (fmode) {
-                if constexpr (L1F) {
+                if constexpr (L1F && NS == 3) {
+                    // H1 = relu(D1) (the bias went in as C): D register 4q + e of a lane is channel 32c + 8q + 4 half + e
+                    const int q = j4;
+                    unsigned lo[3], hi[3];
+                    split_planes<3>(relu_bits(d1[4 * q]), relu_bits(d1[4 * q + 1]), lo);
+                    split_planes<3>(relu_bits(d1[4 * q + 2]), relu_bits(d1[4 * q + 3]), hi);
+#pragma unroll
+                    for (int s_ = 0; s_ < 3; ++s_) {
+                        bp[q >> 1][s_][(q & 1) * 2 + 0] = lo[s_];
+                        bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
+                    }
+                }
+                if constexpr (L1F && NS == 2) {
                     // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1): D register 4q + e of a lane is channel 32c + 8q + 4 half + e
                     const int q = j4;
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
@@ -1007,7 +1066,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
   }
 }
 
-template <int C1, int C2, int C3, int NS>
+template <int C1, int C2, int C3, int NS, int MODE = 0>
 int launch_sab(SaBP p, hipStream_t st) {
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     static const bool streamed_only = getenv("EV2H_SA_STREAMED") != nullptr;      // A/B switch for the resident variant
@@ -1017,7 +1076,7 @@ int launch_sab(SaBP p, hipStream_t st) {
             std::atomic<int>& wg = wg_slot.cur();
             int wg_per_cu = wg.load(std::memory_order_acquire);
             if (!wg_per_cu) {
-                auto k = sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true>;
+                auto k = sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true, MODE>;
                 EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::RES_LDS_BYTES));
                 int n = 0;
                 EV2H_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SAB_THREADS, Cfg::RES_LDS_BYTES));
@@ -1028,14 +1087,14 @@ int launch_sab(SaBP p, hipStream_t st) {
             const int want = 256 * wg_per_cu;                                   // one resident wave of workgroups
             p.per_xcd = ceil_div(ceil_div(ngroups, 8), SAB_WAVES) * SAB_WAVES;
             p.nblk = 8 * std::min(want / 8, ceil_div(p.per_xcd, SAB_WAVES));
-            sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true><<<p.nblk, SAB_THREADS, Cfg::RES_LDS_BYTES, st>>>(p);
+            sa_mlp_max_bf16_kernel<C1, C2, C3, NS, true, MODE><<<p.nblk, SAB_THREADS, Cfg::RES_LDS_BYTES, st>>>(p);
             EV2H_CHECK_LAUNCH();
             return EV2H_OK;
         }
     }
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false>),
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES)););
     {
         // small grids (a few windows at a time): spread a group's strips over the waves of a workgroup (SaBP::spg).  Chosen by the
@@ -1047,18 +1106,21 @@ int launch_sab(SaBP p, hipStream_t st) {
             p.nblk = ceil_div(p.B * p.S, SAB_WAVES / spg);
         }
     }
-    sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
+    sa_mlp_max_bf16_kernel<C1, C2, C3, NS, false, MODE><<<p.nblk, SAB_THREADS, Cfg::LDS_BYTES, st>>>(p);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
 
-template <int NS>
+template <int NS, int MODE = 0>
 int dispatch_sab(const SaBP& p, int c1, int c2, int c3, hipStream_t st) {
-    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sab<32, 32, 64, NS>(p, st);
-    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sab<64, 64, 128, NS>(p, st);
-    if (c1 == 64 && c2 == 96 && c3 == 128) return launch_sab<64, 96, 128, NS>(p, st);
-    if (c1 == 128 && c2 == 128 && c3 == 256) return launch_sab<128, 128, 256, NS>(p, st);
-    if (c1 == 128 && c2 == 196 && c3 == 256) return launch_sab<128, 196, 256, NS>(p, st);
+    if constexpr (NS == 3 && MODE == 0) {
+        if (p.feat) return dispatch_sab<3, 3>(p, c1, c2, c3, st);       // raw feature rows: the feature-row instantiations
+    }
+    if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sab<32, 32, 64, NS, MODE>(p, st);
+    if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sab<64, 64, 128, NS, MODE>(p, st);
+    if (c1 == 64 && c2 == 96 && c3 == 128) return launch_sab<64, 96, 128, NS, MODE>(p, st);
+    if (c1 == 128 && c2 == 128 && c3 == 256) return launch_sab<128, 128, 256, NS, MODE>(p, st);
+    if (c1 == 128 && c2 == 196 && c3 == 256) return launch_sab<128, 196, 256, NS, MODE>(p, st);
     ev2h_set_error("ev2h_sa_mlp_max: unsupported MLP widths %d-%d-%d", c1, c2, c3);
     return EV2H_ERR_ARG;
 }
@@ -1172,7 +1234,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * d->S, SAB_WAVES);
     if (d->feat) {
-        EV2H_CHECK_ARG((d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_F16X2) && d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 &&
+        EV2H_CHECK_ARG(d->W1f && d->b1 && d->nfeat >= 0 && d->nfeat <= 5 &&
                        d->ldf >= 8 && (d->ldf % 4) == 0 && d->ldw1f >= d->nfeat);
         p.feat = d->feat; p.ldf = d->ldf; p.W1f = d->W1f; p.ldw1f = d->ldw1f; p.b1 = d->b1; p.nfeat = d->nfeat;
         p.u1f = d->w1f_unscale > 0.f ? d->w1f_unscale : 1.f;

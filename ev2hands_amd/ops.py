@@ -142,10 +142,10 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped.
     p1_scale [B] float32 / p1_amax [B] range record / dmax / out_amax: the F16X2 range arguments of ev2h_sa_desc (P1 then
     holds p1_scale[b] * table)."""
-    if feat is not None and P1 is None and precision not in ("bf16", "f16x2"):
-        raise ValueError(f"sa_mlp_max: feature rows without a layer-1 table need precision 'bf16' or 'f16x2', not {precision!r}")
+    if feat is not None and P1 is None and precision not in ("bf16", "f16x2", "bf16x3"):
+        raise ValueError(f"sa_mlp_max: feature rows without a layer-1 table need a plane precision ('bf16', 'f16x2', 'bf16x3'), not {precision!r}")
     if feat is not None:
-        # "bf16" / "f16x2": layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
+        # "bf16" / "f16x2" / "bf16x3": layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
         # b1 [C1] -- no table (P1 may be None); feat_amax [B] range record of the rows + dmax: F16X2 range handling
         B, Npts, C1 = feat.shape[0], feat.shape[1], W1x.shape[0]
         dev = feat.device

@@ -52,7 +52,7 @@ typedef void* ev2h_stream_t; /* hipStream_t */
  *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3).
  * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the one-row-per-
  * window layers (ev2h_gemm_desc.skinny), the folded attention product (ev2h_attn_sim_folded) and -- where they are still computed
- * (F32, BF16X3; EV2H_L1_TABLE=1) -- the K = 8 layer-1 tables of the raw cloud.  In F16X2 and BF16 ev2h_forward runs layer 1 of the set
+ * (F32; EV2H_L1_TABLE=1) -- the K = 8 layer-1 tables of the raw cloud.  In the three plane modes ev2h_forward runs layer 1 of the set
  * abstractions that read raw feature rows on the matrix pipe (ev2h_sa_desc.feat), without a table. */
 #define EV2H_PREC_F32 0
 #define EV2H_PREC_BF16 1
@@ -208,10 +208,11 @@ typedef struct ev2h_sa_desc {
     float w2_norm;               /* max row L1 norm of W2                                                               */
     float b2_max;                /* max |b2|                                                                            */
     uint32_t* out_amax;          /* [B] range record of `out` (atomicMax), optional                                     */
-    /* BF16 and F16X2, optional: layer 1 straight from the raw feature rows, on the matrix pipe -- P1 is then not needed (may be NULL)
+    /* plane modes (BF16, F16X2, BF16X3), optional: layer 1 straight from the raw feature rows, on the matrix pipe -- P1 is then not needed (may be NULL)
      * and no layer-1 table has to be computed or gathered: feat [B][Npts][ldf] (first nfeat <= 5 columns used, ldf >= 8: the forward's
      * feat8 / hf8 rows), W1f [C1][ldw1f] and b1 [C1] the folded layer-1 feature weights and bias of this branch.
-     * BF16: inputs enter as two bf16 planes (16 bits), weights as bf16.  F16X2: every neighbour's feature values and relative xyz are
+     * BF16: inputs enter as two bf16 planes (16 bits), weights as bf16.  BF16X3: inputs and weights as their exact three bf16 planes,
+     * the six plane products of the mode, no factors.  F16X2: every neighbour's feature values and relative xyz are
      * scaled by powers of two of their OWN (derived from that neighbour's maxima and from the two weight blocks' plane factors
      * w1f_unscale / w1x_unscale = ev2h_plane_unscale of W1f and of W1x), so a neighbour's values keep 22 bits relative to its own
      * largest term whatever the rest of the window holds; range handling (optional): feat_amax [B] = the range record of the feature rows,

@@ -413,6 +413,47 @@ def test_sa_mlp_max_bf16_layer1_from_raw_features(C1, C2, C3, K, nfeat):
     assert e_ref < 2e-2 and e_tab < 2e-2
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-3, 3e4])
+@pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
+def test_sa_mlp_max_bf16x3_layer1_from_raw_features(C1, C2, C3, K, mag):
+    """[r5] BF16X3: layer 1 on the matrix pipe straight from the raw feature rows (three MFMAs per chunk = the six plane products, the
+    bias as the accumulator's start, no factors), same construction as the F16X2 test -- features of magnitude `mag` next to O(1)
+    coordinates and a 1e6 x hot pixel in every group -- fp32-class against the float64 restatement of pointnet2_utils.py:244-257,
+    and against the table form of the same mode (exact fp32 layer 1)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    B, Npts, S, nfeat = 2, 512, 37, 5
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, C1 + C2 + 3) * sc).float()
+    feat = torch.zeros(B, Npts, 8)
+    feat[:, :, :nfeat] = g("feat", (B, Npts, nfeat)) * mag
+    feat[:, 7, 3] = mag * 1e6                                      # the hot pixel
+    xyz = cloud_xyz("U", B, Npts, 47)
+    ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), C3 + 2)).int()
+    gidx[:, :, 1] = 7                                               # every group sees it
+    W1f, b1, W1x = g("W1f", (C1, nfeat), 0.4 / mag), g("b1", (C1,), 0.1), g("W1x", (C1, 3), 0.5)
+    W2, b2 = g("W2", (C2, C1), C1 ** -0.5), g("b2", (C2,), 0.1)
+    W3, b3 = g("W3", (C3, C2), C2 ** -0.5), g("b3", (C3,), 0.1)
+    bi = torch.arange(B).view(B, 1, 1)
+    f_rows = feat[:, :, :nfeat].double()[bi, gidx.long()]
+    dxyz = (xyz[bi, gidx.long()] - ctr.view(B, S, 1, 3)).double()
+    h1 = (f_rows @ W1f.double().t() + b1.double() + dxyz @ W1x.double().t()).clamp_min(0)
+    h2 = (h1 @ W2.double().t() + b2.double()).clamp_min(0)
+    ref = (h2 @ W3.double().t() + b3.double()).clamp_min(0).max(2)[0]
+    up = lambda x, m: (x + m - 1) // m * m
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = W1x
+    W2p = torch.zeros(up(C2, 32), C1); W2p[:C2] = W2
+    b2p = torch.zeros(up(C2, 32)); b2p[:C2] = b2
+    W3p = torch.zeros(C3, up(C2, 8)); W3p[:, :C2] = W3
+    args = (ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2p.cuda(), b2p.cuda(), W3p.cuda(), b3.cuda(), C2, "bf16x3")
+    got = ops.sa_mlp_max(None, *args, feat=feat.cuda(), W1f=W1f.cuda(), b1=b1.cuda())
+    P1 = (feat[:, :, :nfeat].double() @ W1f.double().t() + b1.double()).float().cuda()
+    table = ops.sa_mlp_max(P1, *args)
+    e_ref, e_tab = rel(got, ref), rel(got, table)
+    print(f"sa<{C1},{C2},{C3}> bf16x3 layer 1 from raw features (|f| ~ {mag:g}, hot pixel x1e6): vs float64 {e_ref:.2e}, vs the table form {e_tab:.2e}")
+    assert torch.isfinite(got).all() and e_ref < 8e-6 and e_tab < 8e-6
+
+
 @pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "bf16"])
 @pytest.mark.parametrize("C1,C2,C3,K", [(64, 96, 128, 128), (128, 196, 256, 128), (128, 128, 256, 64)])
 def test_sa_mlp_max_skips_padding_strips(C1, C2, C3, K, precision):
