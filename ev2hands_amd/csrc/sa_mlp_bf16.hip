@@ -77,6 +77,17 @@ __device__ long long g_sab_timeline[256];
 #else
 #define STAMP(i) do { } while (0)
 #endif
+// The table form and the feature-row form of the set abstraction (ev2h_sa_desc.feat) are SEPARATE INSTANTIATIONS (MODE 0 / MODE 3) [r5]:
+// one body that chooses at run time keeps both forms' registers live (128-196-256: 249 registers instead of 224 / 214 in F16X2, a
+// 92-byte spill in BF16X3; the BF16 feature-row kernels 158 -> 124, which doubles the resident workgroups per CU) and schedules around
+// the branch.  Same-box: F16X2 step +2.3 %, BF16 +4 % (profiles/r5_ab_split_forms.txt).
+// EV2H_BUILD_DEFS=-DEV2H_NO_SPLIT_FORMS: BF16 and F16X2 as one body again (A/B; BF16X3 has no such build -- it would spill).
+#ifdef EV2H_NO_SPLIT_FORMS
+constexpr bool SAB_SPLIT12 = false;
+#else
+constexpr bool SAB_SPLIT12 = true;
+#endif
+template <int NS> constexpr bool sab_split_forms() { return NS == 3 || SAB_SPLIT12; }
 constexpr int SAB_WAVES = 8;
 constexpr int SAB_THREADS = SAB_WAVES * 64;
 
@@ -140,11 +151,10 @@ struct SaBCfg {
 template <int C1, int C2, int C3, int NS, bool RES, int MODE = 0>
 __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
     constexpr int WV = SAB_WAVES;
-    // MODE = 3 (BF16X3 only): the set abstraction with RAW FEATURE ROWS compiled in (L1F below) -- in BF16 / F16X2 the table and the
-    //              feature form share one kernel and choose at run time; the three-plane kernels have no registers left for both
-    //              (the 128-196-256 instantiation spilled 92 bytes), so each form is its own instantiation there.
+    // MODE = 3: the set abstraction with RAW FEATURE ROWS compiled in (L1M / L1F below; MODE 0 is then the table form only) -- see
+    //              sab_split_forms above.
     constexpr bool ROWS = MODE == 1 || MODE == 2, DIRECT = MODE == 2;
-    static_assert(MODE != 3 || NS == 3, "MODE 3 is the BF16X3 feature-row form");
+    static_assert(MODE != 3 || sab_split_forms<NS>(), "MODE 3 is the feature-row form of the modes that compile it separately");
     static_assert(!(RES && ROWS), "the row-output variants stream their tiles");
     // BF16, set abstraction: LAYER 1 ON THE MATRIX PIPE.  D1[channel][neighbour] = A1 [32 channels][16 k] x B1 [16 k][32 neighbours]
     // (+ C = the gathered table row when the features are a table) with the k slots
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // BF16X3 with raw feature rows [r5]: the same without any factor.  B1f = [x0(8) | x1(8)], B1g = [x0 | x2] (x = x0 + x1 + x2, the exact
     // three-plane split), A = [w2 | w0] (x B1g), [w1 | w1], [w0 | w0] (x B1f): three MFMAs = the six products of Planes<3>, small terms
     // first, on top of C = b1.
-    constexpr bool L1F = !ROWS && (NS == 2 || (NS == 3 && MODE == 3));
+    constexpr bool L1F = !ROWS && NS >= 2 && (!sab_split_forms<NS>() || MODE == 3);
     // L2PIPE / H2FUSE (round 4, late): conversion work of one wave placed between its MFMA groups (see the layer-2 loop and the first
     // layer-3 step).  Same-box step A/B (profiles/r4_ab_h2fuse_l2pipe.txt): BF16 +1.3 % with H2FUSE, +1.9 % with both; F16X2 +1.1 % with
     // H2FUSE, and L2PIPE costs it 0.5 % (its widest instantiation then spills 24 bytes) -- so F16X2 keeps the un-pipelined layer 2.
@@ -178,7 +188,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #ifdef EV2H_NO_L2PIPE
     constexpr bool L2PIPE = false;
 #else
+#ifdef EV2H_L2PIPE2
+    constexpr bool L2PIPE = !ROWS && NS <= 2 && (C1 / 32) % 2 == 0;      // build experiment: F16X2 too
+#else
     constexpr bool L2PIPE = !ROWS && NS == 1 && (C1 / 32) % 2 == 0;
+#endif
 #endif
 #ifdef EV2H_NO_H2FUSE
     constexpr bool H2FUSE = false;
@@ -205,7 +219,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const int half = lane >> 5, l31 = lane & 31;
     const int L = xcd_remap(blockIdx.x, p.nblk);
     const int ngroups = p.B * p.S;
-    const bool fmode = (NS == 3) ? (MODE == 3) : (L1F && p.feat != nullptr);               // (uniform; BF16X3: a compile-time constant)
+    // hasfeat: the features are raw rows (ev2h_sa_desc.feat) -- a compile-time constant where the two forms are separate instantiations
+    const bool hasfeat = sab_split_forms<NS>() ? (MODE == 3) : (p.feat != nullptr);
+    const bool fmode = L1F && hasfeat;                         // (uniform)
     // F16X2 feature mode: s1 b1 of this wave's window; BF16X3 feature mode: b1 (one copy)
     float* sb1w = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * 96);
 
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
             for (int j = 0; j < 16; ++j) k[j] = 0.f;
             k[5] = k[8] = w.x; k[6] = k[9] = w.y; k[7] = k[10] = w.z;
-            if (p.feat) {
+            if (hasfeat) {
                 for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) k[12 + j] = k[j];
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     if constexpr (XPF) {
         idx_cur = gi[l31];
         q_cur = p.pts4[(size_t)b * p.Npts + idx_cur];
-        if (p.feat) {
+        if (hasfeat) {
             const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_cur) * p.ldf);
             f0_cur = fr[0]; f1_cur = fr[1];
         }
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 float f[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = 0.f;
-                if (p.feat) {
+                if (hasfeat) {
                     f[0] = f0_cur.x; f[1] = f0_cur.y; f[2] = f0_cur.z; f[3] = f0_cur.w; f[4] = f1_cur.x;
                 } else {
                     prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp);
@@ -555,7 +571,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 acc = mfma_planes<2>(al, b1f, acc);
                 return mfma_planes<2>(ah, b1f, acc);
             } else {
-            if (p.feat) {
+            if (hasfeat) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             } else {
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         if constexpr (L1F) { if (fmode) d1 = layer1(0); }
         if constexpr (L1M) {
             d1 = layer1(0);
-            if (!p.feat && NC1 > 1) {
+            if (!hasfeat && NC1 > 1) {
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + 8 + qi(j4));
             }
@@ -744,7 +760,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     // (table mode) was loaded one iteration ago, the row after it is requested now
                     if (c + 1 < NC1) {
                         d1 = layer1(c + 1);
-                        if (!p.feat && c + 2 < NC1) {
+                        if (!hasfeat && c + 2 < NC1) {
 #pragma unroll
                             for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
                         }
@@ -772,7 +788,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     if constexpr (L1F) { if (fmode) d1 = layer1(c + 1); }
                     if constexpr (L1M) {
                         d1 = layer1(c + 1);
-                        if (!p.feat && c + 2 < NC1) {
+                        if (!hasfeat && c + 2 < NC1) {
 #pragma unroll
                             for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + (c + 2) * 8 + qi(j4));
                         }
@@ -806,7 +822,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             // next strip's coordinates and feature row / first table chunk: its index arrived long ago; `raw` is free again
             if (strip + 1 < my_strips) {
                 q_cur = p.pts4[(size_t)b * p.Npts + idx_nxt];
-                if (p.feat) {
+                if (hasfeat) {
                     const float4* fr = reinterpret_cast<const float4*>(p.feat + ((size_t)b * p.Npts + idx_nxt) * p.ldf);
                     f0_cur = fr[0]; f1_cur = fr[1];
                 } else {
@@ -1113,8 +1129,8 @@ int launch_sab(SaBP p, hipStream_t st) {
 
 template <int NS, int MODE = 0>
 int dispatch_sab(const SaBP& p, int c1, int c2, int c3, hipStream_t st) {
-    if constexpr (NS == 3 && MODE == 0) {
-        if (p.feat) return dispatch_sab<3, 3>(p, c1, c2, c3, st);       // raw feature rows: the feature-row instantiations
+    if constexpr (sab_split_forms<NS>() && MODE == 0) {
+        if (p.feat) return dispatch_sab<NS, 3>(p, c1, c2, c3, st);      // raw feature rows: the feature-row instantiations
     }
     if (c1 == 32 && c2 == 32 && c3 == 64) return launch_sab<32, 32, 64, NS, MODE>(p, st);
     if (c1 == 64 && c2 == 64 && c3 == 128) return launch_sab<64, 64, 128, NS, MODE>(p, st);
