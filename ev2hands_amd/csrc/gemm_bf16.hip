@@ -596,8 +596,11 @@ struct GOCfg {
 // k and written behind them.  With three workgroups per CU the other two hide a workgroup's load -> split -> barrier chain; a launch
 // of 2..8 workgroups (one window at a time: every M = 128 B layer) has nobody to hide it, and its time is (K / 32) x that chain.
 // Same tiles, same MFMA order: bit-identical to the single-buffer kernel, so the choice (by launch size) never shows in a result.
-template <int NS, bool TAP3, bool PIPE = false>
+// ZS (TAP3 only): the epilogue forms the attention's key-weighted sums instead of storing the tile (zsum_epilogue) -- its own
+// instantiation, not a run-time choice inside one body (see sab_split_forms in sa_mlp_bf16.hip for what one body with two forms costs)
+template <int NS, bool TAP3, bool PIPE = false, bool ZS = false>
 __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP p, const char* __restrict__ Ws) {
+    static_assert(!ZS || TAP3, "the q1-free epilogue belongs to the tap kernel");
     using Cfg = GOCfg<NS, TAP3>;
     constexpr int RS = Cfg::RS;
     static_assert(!(PIPE && TAP3), "the pipelined variant is for the plain K loop");
@@ -823,19 +826,25 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         }
     }
 
-    if constexpr (TAP3) {             // (NS = 3: two registers of the epilogue's straight-line code go to scratch; the tap loop has none)
+    if constexpr (ZS) {
+        zsum_epilogue<NS>(p, acc, m0, wm, wn, n0, smem, tid);
+        return;
+    }
+#ifdef EV2H_GEMM_ONE_BODY            // build A/B: both epilogues in the tap kernel's one body, chosen at run time (the form until round 5)
+    if constexpr (TAP3) {
         if (p.zs_out) { zsum_epilogue<NS>(p, acc, m0, wm, wn, n0, smem, tid); return; }
     }
+#endif
     gemm_epilogue<NS, 2, 2, false>(p, acc, m0, wm * 64, n0 + wn * 64, wm, wn * 64, GO_BN, reinterpret_cast<float*>(smem), tid);
 }
 
-template <int NS, bool TAP3>
+template <int NS, bool TAP3, bool ZS = false>
 int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS, TAP3>),
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_occ_kernel<NS, TAP3, false, ZS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GOCfg<NS, TAP3>::LDS_BYTES)););
-    gemm_nt_bf16_occ_kernel<NS, TAP3><<<p.nblk, GO_THREADS, GOCfg<NS, TAP3>::LDS_BYTES, st>>>(p, Ws);
+    gemm_nt_bf16_occ_kernel<NS, TAP3, false, ZS><<<p.nblk, GO_THREADS, GOCfg<NS, TAP3>::LDS_BYTES, st>>>(p, Ws);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
@@ -1014,9 +1023,14 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     p.x_bf16 = x_bf16;
     p.tiles_n = d->N / GO_BN;
     p.nblk = (d->M / GB_BM) * p.tiles_n;
-    if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true>(p, (const char*)d->Ws, (hipStream_t)stream);
-    if (d->precision == EV2H_PREC_BF16) return launch_go_t<1, true>(p, (const char*)d->Ws, (hipStream_t)stream);
-    if (d->precision == EV2H_PREC_BF16X3) return launch_go_t<3, true>(p, (const char*)d->Ws, (hipStream_t)stream);
+#ifdef EV2H_GEMM_ONE_BODY
+    constexpr bool ZS = false;
+#else
+    constexpr bool ZS = true;
+#endif
+    if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16) return launch_go_t<1, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_BF16X3) return launch_go_t<3, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
     return EV2H_ERR_ARG;
 }
 
