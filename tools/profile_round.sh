@@ -21,7 +21,7 @@ export EV2H_TWO_STREAMS=0
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_f16x2_ss -o bench -- $PY $BENCH --precision f16x2 > $O/${TAG}_ktlog_f16x2_single_stream.txt 2>&1
 python tools/rocpd_summary.py $(ls $O/${TAG}_kt_f16x2_ss/*/*.db $O/${TAG}_kt_f16x2_ss/*.db 2>/dev/null | head -1) --sites "128, 196, 256" 3 > $O/${TAG}_bench_kernel_stats_f16x2_single_stream.txt 2>&1
 # the HIP-event time of site 0 (sa2.1) measured by bench.py in the SAME profiled command, next to the trace's per-site averages
-grep -o '"kernel_ms": [0-9.]*' $O/${TAG}_ktlog_f16x2_single_stream.txt | head -1 | sed 's/^/# bench.py HIP events around site 0 in the same command: /' >> $O/${TAG}_bench_kernel_stats_f16x2_single_stream.txt
+grep -o '"kernel_ms": [0-9.]*' $O/${TAG}_ktlog_f16x2_single_stream.txt | head -1 | sed 's/^/# bench.py HIP events around site sa2.1 (the table form) in the same command: /' >> $O/${TAG}_bench_kernel_stats_f16x2_single_stream.txt
 unset EV2H_TWO_STREAMS
 for prec in f16x2 bf16 f32; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_fetch_$prec -o p -- $PY $SMALL --precision $prec > $O/${TAG}_pmc_fetch_$prec.log 2>&1

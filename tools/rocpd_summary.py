@@ -1,9 +1,11 @@
 """Summarise a rocprofv3 (ROCm 7.2) rocpd sqlite database: per-kernel calls / total / average / MEDIAN duration,
 keyed by kernel name + grid so differently shaped launches of one template stay apart.
 usage: python tools/rocpd_summary.py gpurun_out/prof/xyz_results.db [--skip-first K] [--sites SUBSTRING N]
---sites SUBSTRING N: a kernel that one forward launches at N sites with the same grid (the 128-196-256 SA kernel: enc.sa2 branch 1,
-then the two hands' mano.sa1 branch 1) is also listed per site (dispatch order modulo N), so that the site bench.py brackets with
-HIP events (sa2.1 = site 0) can be compared with its own trace average instead of the average over three different inputs.
+--sites SUBSTRING N: the kernels whose name holds SUBSTRING are launched at N sites per forward in all (the 128-196-256 SA kernels:
+enc.sa2 branch 1 -- the table form, one instantiation -- then the two hands' mano.sa1 branch 1 -- the feature-row form, another
+instantiation since round 5); each such kernel is also listed per site (its share of the N sites, dispatch order modulo that share),
+so that the site bench.py brackets with HIP events (sa2.1 = the table form's only site) can be compared with its own trace average
+instead of the average over three different inputs.
 --skip-first K (default 1) drops the first K dispatches of every (kernel, grid) key: the very first launch of a kernel pays code
 loading / page faults (round 2's table had a 22 ms `ball_query` outlier turning a 4 % kernel into "14.6 %"); the `%` column is
 computed from the remaining dispatches, and the median is printed next to the average so that an outlier shows."""
@@ -56,8 +58,9 @@ def main():
 
 
     if sites:
+        total = sum(len(d) for d in site_durs.values())
         for key, durs in site_durs.items():
-            n = sites[1]
+            n = max(1, round(len(durs) * sites[1] / max(total, 1)))      # this kernel's share of the N sites of a forward
             print(f"# launch sites of {key[0]} ({key[1] * max(key[2], 1)} blocks), dispatch order modulo {n}, first forward dropped:")
             for k in range(n):
                 d = durs[n + k::n]
