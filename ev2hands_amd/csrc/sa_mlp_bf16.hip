@@ -199,10 +199,13 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #else
     constexpr bool H2FUSE = NS <= 2;          // (BF16X3: the widest instantiation would spill)
 #endif
-#ifdef EV2H_FRAG_PIPE_ALL
-    constexpr bool FRAG_PIPE = true;
-#else
+    // F16X2 [r5]: with the two layer-1 forms in separate instantiations there are registers for the second fragment set (128-196-256:
+    // 224 -> 232): dominant launch 1.622 -> 1.592 ms, step +0.65 % same-box (profiles/r5_ab_frag_pipe_f16x2.txt).  BF16X3 would spill
+    // (28 bytes in the widest instantiation).  EV2H_BUILD_DEFS=-DEV2H_NO_FRAG_PIPE2: F16X2 without (A/B).
+#ifdef EV2H_NO_FRAG_PIPE2
     constexpr bool FRAG_PIPE = (NS == 1);
+#else
+    constexpr bool FRAG_PIPE = (NS <= 2);
 #endif
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
