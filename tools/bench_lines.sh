@@ -13,5 +13,6 @@ python bench.py --points 8192 --batch 128 --steps 60 --collision --collision-mes
 # config 5 read as an 8-GPU shard (B = 128 over 8 ranks): 16 windows of 8192 points per rank
 python bench.py --points 8192 --batch 16 --steps 200 $Q 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16.json
 python bench.py --points 8192 --batch 16 --steps 200 --collision $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_collision.json
+python bench.py --points 8192 --batch 16 --steps 200 --collision --inflight 2 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_collision_inflight2.json
 EV2H_BENCH_FORCE_DIST=1 python bench.py $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_force_dist.json
 for f in $O/${TAG}_bench_line_*.json; do python -c "import json,sys; j=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', j['value'], j['ms_per_step'], j.get('pcie_inclusive',{}).get('value'), j['roofline']['frac'])"; done
