@@ -71,7 +71,12 @@ __device__ bool sat_intersect(const V3 (&a)[3], const V3 (&b)[3]) {
     return true;
 }
 
+// SPLIT / PHASE: the call forms are separate instantiations (one workgroup per window: <false, 0>; two per window: <true, 0> counting
+// walk, <true, 1> prefix sums + compaction, <true, 2> list walk) -- one body with run-time tests of p.nsplit / p.phase sat at the
+// 128-register cap of a 1024-thread workgroup with 19 registers in scratch
+template <bool SPLIT, int PHASE>
 __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
+    static_assert(SPLIT || PHASE == 0, "phases belong to the split form");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int V2 = 2 * p.nv, F2 = 2 * p.nf;
     float* sv = reinterpret_cast<float*>(smem);                 // [V2][3] mm
@@ -81,23 +86,24 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     int* spart = srow + F2 + 1;                                 // [COL_THREADS] scan scratch
     int* squeue = spart + COL_THREADS + (threadIdx.x >> 6) * 128;   // [waves][128] this wave's candidates: (lane << 16) | column
     float* sblk = reinterpret_cast<float*>(spart + COL_THREADS + (COL_THREADS >> 6) * 128);   // [nblk][6] box of every 64-triangle block
-    const int wgs = p.phase == 1 ? 1 : p.nsplit;              // (phase 1 runs one workgroup per window)
+    const int nsplit = SPLIT ? p.nsplit : 1;
+    const int wgs = PHASE == 1 ? 1 : nsplit;                  // (phase 1 runs one workgroup per window)
     const int b = blockIdx.x / wgs, wg = blockIdx.x % wgs, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t* grow = p.rowcnt ? p.rowcnt + (size_t)b * (F2 + 1) : nullptr;
 
-    if (p.phase != 1)
+    if constexpr (PHASE != 1)
     for (int i = tid; i < 3 * V2; i += COL_THREADS) {
         const int v = i / 3, c = i - 3 * v;
         const float x = v < p.nv ? p.vl[((size_t)b * p.nv + v) * 3 + c] : p.vr[((size_t)b * p.nv + (v - p.nv)) * 3 + c];
         sv[i] = __fmul_rn(x, p.scale);                          // float32 multiply like `.numpy() * 1000`
     }
-    if (p.phase != 1)
+    if constexpr (PHASE != 1)
     for (int i = tid; i < 3 * F2; i += COL_THREADS) {
         const int f = i / 3, c = i - 3 * f;
         sf[i] = f < p.nf ? p.fl[f * 3 + c] : p.fr[(f - p.nf) * 3 + c] + p.nv;
     }
     __syncthreads();
-    if (p.phase != 1)
+    if constexpr (PHASE != 1)
     for (int f = tid; f < F2; f += COL_THREADS) {
         float lo[3], hi[3];
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     // their order and therefore the counts, caps and pair lists are exactly those of the full walk.  Mesh faces are stored
     // locally coherent (a block is a patch of the surface), and the two hands are usually apart: a hand-like pair of meshes
     // keeps ~1/8 of the block pairs (profiles/r3_collision_timing.txt); random triangle soup keeps all of them.
-    if (p.phase != 1) {
+    if constexpr (PHASE != 1) {
         const int nblk_ = (F2 + 63) >> 6;
         for (int kb = wave; kb < nblk_; kb += (COL_THREADS >> 6)) {
             const int f = kb * 64 + lane;
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
     // so dealing them round-robin gave the first wave 100 column blocks and the last 54 (49 row blocks, 16 waves); boustrophedon
     // rounds level that (84 / 70), and with two workgroups per window no wave has more than block 0's 49.  A row's result does not
     // depend on who computes it.
-    const int NW = nwaves * p.nsplit, gw = wg * nwaves + wave;
+    const int NW = nwaves * nsplit, gw = wg * nwaves + wave;
     auto walk = [&](int pass) {
         for (int rnd = 0; rnd * NW < nblk; ++rnd) {
             const int rb = rnd * NW + ((rnd & 1) ? NW - 1 - gw : gw);
@@ -215,21 +221,21 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
             }
             }
             while (qn > 0) drain(min(qn, 64));
-            if (!pass && valid) { if (p.nsplit > 1) grow[i] = cnt; else srow[i] = cnt; }
+            if (!pass && valid) { if constexpr (SPLIT) grow[i] = cnt; else srow[i] = cnt; }
         }
     };
-    if (p.nsplit > 1 && p.phase == 0) { walk(0); return; }
-    if (p.nsplit > 1 && p.phase == 2) {                          // bases = the exclusive prefix phase 1 left in rowcnt
+    if constexpr (SPLIT && PHASE == 0) { walk(0); return; }
+    if constexpr (SPLIT && PHASE == 2) {                         // bases = the exclusive prefix phase 1 left in rowcnt
         for (int r = tid; r <= F2; r += COL_THREADS) srow[r] = grow[r];
         __syncthreads();
         walk(1);
         return;
     }
-    if (p.nsplit > 1) {                                          // phase 1: the row counts of all workgroups
+    if constexpr (SPLIT) {                                       // phase 1: the row counts of all workgroups
         for (int r = tid; r < F2; r += COL_THREADS) srow[r] = grow[r];
     }
     for (int pass = 0; pass < 2; ++pass) {
-        if (p.nsplit == 1) walk(pass);
+        if constexpr (!SPLIT) walk(pass);
         if (pass) break;
         __syncthreads();
         // exclusive prefix sum of srow[0..F2): each thread sums a contiguous chunk, Hillis-Steele over the chunk totals
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(COL_THREADS) void mesh_collision_kernel(ColP p) {
         if (tid == COL_THREADS - 1) { p.counts[b] = spart[tid]; srow[F2] = spart[tid]; }
         if (!out) break;                                        // counts only: the second walk would repeat every test for nothing
         __syncthreads();
-        if (p.nsplit > 1 && !one_walk) {                         // phase 2 (another launch) writes the pairs at these bases
+        if (SPLIT && !one_walk) {                                // phase 2 (another launch) writes the pairs at these bases
             for (int r = tid; r <= F2; r += COL_THREADS) grow[r] = srow[r];
             break;
         }
@@ -372,29 +378,31 @@ extern "C" int ev2h_mesh_collisions_ws(const float* verts_left, const float* ver
                        COL_THREADS * 4 + (COL_THREADS / 64) * 128 * 4 + (size_t)((2 * nf + 63) / 64) * 6 * 4;
     static PerDevice attr_set{};
     EV2H_ONCE_PER_DEVICE(attr_set,
-        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024)););
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel<false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel<true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        EV2H_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mesh_collision_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)););
     // One 1024-thread workgroup (142 KB of LDS) per window fills one CU: below 256 windows CUs idle (BASELINE config 5 runs B = 128 per
     // GPU).  With a scratch buffer a window's row blocks are split over two workgroups (more cannot help: row block 0 alone scans all
     // 49 column blocks).  The caller chooses: no scratch buffer = one workgroup per window.
     const int nsplit = (scratch && scratch_bytes >= ev2h_mesh_collisions_scratch_bytes(B, nf) && B <= 128) ? 2 : 1;
     if (nsplit == 1) {
-        mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+        mesh_collision_kernel<false, 0><<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;
     }
     p.nsplit = nsplit;
     p.rowcnt = static_cast<int32_t*>(scratch);
     p.phase = 0;
-    mesh_collision_kernel<<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+    mesh_collision_kernel<true, 0><<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     p.phase = 1;
-    mesh_collision_kernel<<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+    mesh_collision_kernel<true, 1><<<B, COL_THREADS, lds, (hipStream_t)stream>>>(p);
     EV2H_CHECK_LAUNCH();
     const bool one_walk = pairs && max_per_triangle > 0 && (long)max_pairs >= (long)(2 * nf) * max_per_triangle;
     if (pairs && !one_walk) {
         p.phase = 2;
-        mesh_collision_kernel<<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
+        mesh_collision_kernel<true, 2><<<B * nsplit, COL_THREADS, lds, (hipStream_t)stream>>>(p);
         EV2H_CHECK_LAUNCH();
     }
     return EV2H_OK;
