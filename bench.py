@@ -27,6 +27,7 @@ import os
 import socket
 import subprocess
 import sys
+import math
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,12 +41,14 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0    # same table, dense bf16 / fp16 matrix peak
 # limit (tools/ubench/mfma_power.hip, profiles/r3_mfma_ceiling.txt).  A kernel that also feeds the pipe cannot beat that.
 SUSTAINED_16BIT_MFMA_TFLOPS = 1700.0
 # plane products executed per algorithmic multiply-add in each arithmetic mode
-PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1}
+PRODUCTS = {"f32": 1, "bf16x3": 6, "f16x2": 3, "bf16": 1, "f16": 1}
 DTYPE = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
          "bf16x3": "f32 (each f32 operand split exactly into 3 bf16 planes, 6 plane products per MAC on the bf16 MFMA, f32 accumulate)",
          "f16x2": "f32 (each f32 operand split into 2 fp16 planes with per-window power-of-two range scaling, 3 plane products per MAC "
                   "on the f16 MFMA, f32 accumulate)",
-         "bf16": "bf16 (f32 accumulate)"}
+         "bf16": "bf16 (f32 accumulate)",
+         "f16": "f16 (ONE fp16 plane per operand with f16x2's per-window power-of-two range scaling, 1 product per MAC on the f16 MFMA, "
+                "f32 accumulate; layer 1 of the raw-cloud set abstractions in f16x2's three plane products)"}
 # algorithmic work of the profiled kernel per window: layers 2+3 of enc.sa2 branch 1 (same MLP and group shape as mano.sa1 branch 1;
 # launched before the two-hand stream fork, so its HIP-event duration is free of overlap)
 # (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
@@ -82,7 +85,7 @@ def parse(argv=None):
                     help="random: hash-generated random-init checkpoint (the contract's default); trained: the checkpoint that came out of the "
                          "reference's training loop (tests/trained_ckpt.py) -- same shapes and FLOPs, other bit patterns (dead units, saturated "
                          "softmax): an extra line for profiles/, never the default")
-    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f16x2"), choices=["f32", "bf16x3", "f16x2", "bf16"],
+    ap.add_argument("--precision", default=os.environ.get("EV2H_PRECISION", "f16x2"), choices=["f32", "bf16x3", "f16x2", "bf16", "f16"],
                     help="arithmetic of the MFMA contractions: f16x2 = fp32-class 2-plane fp16 split with per-window range scaling "
                          "(default), bf16x3 = fp32-class 3-plane bf16 split -- both pass the 1e-4 / exact-argmax parity bar, also on "
                          "checkpoints with hidden activations from 1e-4 to 1e+6 -- f32 = v_mfma_f32_32x32x2_f32, bf16 = reduced "
@@ -92,6 +95,8 @@ def parse(argv=None):
     ap.add_argument("--no-latency", action="store_true", help="skip the B=1 / B=8 latency legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-selfcheck", action="store_true", help="skip the two-stream / gather self-checks after the timed region")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg (value_sustained + shader clock)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg's timed region")
     ap.add_argument("--no-second-site", action="store_true", help="skip the short extra run that brackets the second-largest launch (roofline_second)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live HBM-traffic measurement (two rocprofv3 PMC passes of a 3-step child run of this script)")
@@ -258,7 +263,7 @@ def live_pmc_traffic(a, timeout_s=300):
     if not os.path.exists(exe):
         raise RuntimeError("rocprofv3 not found")
     nsteps = 3
-    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site", "--no-host-io",
+    child = [os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-legs", "--no-latency", "--no-cpu-baseline", "--no-traffic", "--no-selfcheck", "--no-second-site", "--no-host-io", "--no-sustained",
              "--precision", a.precision, "--batch", str(a.batch), "--points", str(a.points), "--channels", str(a.channels), "--cloud", a.cloud, "--weights", a.weights]
     tmp = tempfile.mkdtemp(prefix="ev2h_pmc_", dir="/tmp")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EV2H_BENCH_FORCE_DIST")}
@@ -309,6 +314,35 @@ def site_dispatch_values(tag, rows):
     return [v for g, v in gemm if g == gmax]
 
 
+def newest_profile(pattern):
+    """basename of the newest committed profiles/<pattern> by ROUND number (r6_... after r5_...), or None"""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", pattern))
+    if not files:
+        return None
+    rnd = lambda f: int((re.match(r"r(\d+)_", os.path.basename(f)) or [0, 0])[1])      # noqa: E731
+    return os.path.basename(max(files, key=lambda f: (rnd(f), os.path.getmtime(f))))
+
+
+def expected_line_keys(world, a):
+    """The keys rank 0's line of a REAL (non-stub) run carries at this world size and with these switches -- one definition, used by
+    run_rank to check its own line (`line_complete`), by the CPU launcher tests (stub lines list it as `would_emit`: world 2 and 8)
+    and by tests/test_gpu_bench.py on the forced 1-rank RCCL path.  A multi-GPU line is graded like the 1-GPU one: it carries
+    `roofline` (traffic from the committed PMC profile, marked as such) and `cpu_baseline` too."""
+    keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "ms_per_step_per_rank", "roofline", "hbm", "line_complete"]
+    if not a.no_cpu_baseline:
+        keys.append("cpu_baseline")
+    if not a.no_sustained:
+        keys.append("value_sustained")
+    if not a.no_selfcheck:
+        keys.append("multi_gpu_selfcheck")
+    if not a.no_second_site:
+        keys.append("roofline_second")
+    return sorted(keys)
+
+
 def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None, site=None):
     """Dominant-kernel roofline: algorithmic fp32 FLOPs of the layer (2 x MACs) over the HIP-event duration, against the dense peak of
     the matrix pipe the mode uses; the plane products the split modes execute are reported separately."""
@@ -319,18 +353,22 @@ def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None,
     alg_flops = 2.0 * site["mac_per_window"] * B
     alg = alg_flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
     if traffic is None and site["tag"] == PROFILED_TAG:
-        t, src = committed_pmc_traffic(precision)
+        t, src = committed_pmc_traffic(precision if precision != "f16" else "bf16")      # (f16: bf16's images and tile walk; its own profile when committed)
+        t16, src16 = committed_pmc_traffic(precision) if precision == "f16" else (None, None)
+        if t16 is not None:
+            t, src = t16, src16
         if t is not None:
             traffic, traffic_src = t["kernel"], "committed profile profiles/%s (not measured in this run)" % src
+    traffic_kind = None if traffic is None else ("live" if traffic_src and "measured in this run" in traffic_src and "not measured" not in traffic_src else "committed")
     return {"bound": "mfma", "kernel": f"{site['name']}, {B} windows/launch, {precision})", "launch_site": site["tag"],
             "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg / peak, 4),
             "accounting": "algorithmic fp32 multiply-adds x 2 / HIP-event kernel time / dense peak of the MFMA type used",
             "executed": round(alg * nprod, 2), "executed_frac": round(alg * nprod / peak, 4), "products_per_mac": nprod,
             "frac_of_f32_mfma_peak": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
             **({"sustained_peak": SUSTAINED_16BIT_MFMA_TFLOPS, "executed_frac_of_sustained": round(alg * nprod / SUSTAINED_16BIT_MFMA_TFLOPS, 4),
-                "sustained_source": "pure MFMA loop on random operands at the power-limited clock, profiles/r3_mfma_ceiling.txt"}
+                "sustained_source": "pure MFMA loop on random operands at the power-limited clock, profiles/%s" % (newest_profile("r*_mfma_ceiling.txt") or "(none committed)")}
                if precision != "f32" else {}),
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes", "traffic_source": traffic_src,
+            "traffic": traffic, "traffic_kind": traffic_kind, "traffic_unit": "HBM bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) * 1024 from rocprofv3 PMC passes", "traffic_source": traffic_src,
             "kernel_ms": round(kavg, 4), "kernel_samples": len(kernel_ms_list),
             "flop_per_launch": alg_flops}
 
@@ -343,6 +381,7 @@ def hbm_entry(B, N, ms_per_step, step_bytes, source):
     gbs = step_bytes / (ms_per_step * 1e-3) / 1e9 if step_bytes else None
     return {"bound": "hbm", "bytes_per_step": step_bytes, "achieved": round(gbs, 1) if gbs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4) if gbs else None, "source": source,
+            "source_kind": None if not step_bytes else ("live" if source and "measured in this run" in source and "not measured" not in source else "committed"),
             "hbm_time_share_of_step": round(step_bytes / (HBM_PEAK_GBS * 1e9) / (ms_per_step * 1e-3), 4) if step_bytes else None,
             "algorithmic_io_bytes_per_step": int(ALG_IO_BYTES_PER_WINDOW * B * scale),
             "survey_fused_boundary_bytes_per_step": int(SURVEY_FUSED_BYTES_PER_WINDOW * B * scale),
@@ -481,7 +520,7 @@ def run_rank(a) -> int:
             closs = evcol.CollisionLoss(dev)
             dev_faces = (evcol.device_faces(net.hands["left"].faces, dev), evcol.device_faces(net.hands["right"].faces, dev))   # converted ONCE
 
-        if a.inflight > 1:
+        if a.inflight > 1 and not use_dist:            # (with a process group the gather pipeline owns the slots: GatherPipeline(inflight=K))
             from ev2hands_amd.inflight import InflightForward
             infl = InflightForward(net, a.inflight)
 
@@ -498,14 +537,10 @@ def run_rank(a) -> int:
                 out["collision_penalty"] = closs.per_window(out, faces=dev_faces)
             return out
 
-        def forward(rows=None, then=None):
+        def forward(rows=None):
             net.net.fps_init = inits
             if infl is not None:                       # K forwards in flight: returns a ticket, the work is on stream i mod K
-                def post(out):
-                    collision_terms(out)
-                    if then is not None:               # e.g. the asynchronous all-gather of this step, issued behind the forward on ITS stream
-                        then()
-                return infl.submit(xyz, rows=rows, post=post)
+                return infl.submit(xyz, rows=rows, post=collision_terms)
             with torch.no_grad():
                 return collision_terms(net.net(xyz, net.hands, rows=rows))
 
@@ -514,7 +549,8 @@ def run_rank(a) -> int:
     # gather is asynchronous: the xGMI transfer of step i runs under the forward of step i+1 (EV2H_BENCH_SYNC_GATHER=1: in
     # stream order).  The last gather completes inside the timed region (sync() drains the pipeline).
     sync_gather = bool(os.environ.get("EV2H_BENCH_SYNC_GATHER"))
-    pipe = evdist.GatherPipeline(N, gB, dev, depth=1 if sync_gather else 2) if use_dist else None
+    pipe_inflight = a.inflight if (use_dist and not a.stub and a.inflight > 1) else 0
+    pipe = evdist.GatherPipeline(N, gB, dev, depth=1 if sync_gather else 2, inflight=pipe_inflight, net=net if pipe_inflight else None) if use_dist else None
 
     def step():
         if pipe is None:
@@ -522,13 +558,11 @@ def run_rank(a) -> int:
         rows = pipe.rows()
         if a.stub:
             rows.copy_(evdist.pack_outputs(forward()))
-        elif infl is not None:
-            # forwards in flight AND a gather: the collective is issued from the slot's stream right behind its forward (RCCL orders
-            # a collective after the stream it is called on), so that the caller's stream never waits for a forward and the next
-            # submit() is not held back
-            box = []
-            forward(rows, then=lambda: box.append(pipe.submit()))
-            return box[0].result() if sync_gather else box[0]
+        elif pipe_inflight:
+            # forwards in flight AND a gather: one call (dist.GatherPipeline.forward) -- the forward on its slot's stream, the collective
+            # issued from that stream right behind it, the caller's stream never waits for a forward
+            pending = pipe.forward(xyz, fps_init=inits, post=collision_terms)
+            return pending.result() if sync_gather else pending
         else:
             forward(rows)
         pending = pipe.submit()
@@ -544,11 +578,13 @@ def run_rank(a) -> int:
         if not a.stub:
             torch.cuda.synchronize()
 
-    def timed(nsteps):
+    def timed(nsteps, hook=None, every=0):
         sync()
         t0 = time.perf_counter()
-        for _ in range(nsteps):
+        for i in range(nsteps):
             step()
+            if hook is not None and every and i % every == every // 2:
+                hook()
         sync()
         dt_ = time.perf_counter() - t0
         tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
@@ -587,6 +623,31 @@ def run_rank(a) -> int:
         L.ev2h_profile_set(None, None, None, 0)
         second_kernel_ms = ev2.elapsed_ms(k2)
     rank_ms = [round(v / a.steps * 1e3, 3) for v in all_ranks(local_dt)]        # every rank's own wall time per step
+    # value_sustained: the SAME step over a region of >= 2 s, with the shader clock observed while it runs (one-wave probes on a
+    # stream of their own, ev2h_shader_clock_probe).  The matrix-pipe kernels are power-limited on real data (2.39 GHz idle boost ->
+    # ~1.65 GHz under load, profiles/r*_mfma_ceiling.txt): the driver's `--steps 20` region lasts a quarter of a second, so a reader
+    # needs to see whether `value` is a boost-window number.  Never `value`; every rank takes part (collectives inside timed()).
+    sustained = None
+    if not a.stub and not a.no_sustained:
+        from ev2hands_amd import _lib as _evl
+        ms0 = dt / a.steps * 1e3
+        ks = int(min(max(a.steps, math.ceil(a.sustained_seconds * 1e3 / max(ms0, 1e-3))), 20000))
+        smp = _evl.ShaderClockSampler(dev, max_samples=40)
+        torch.cuda.synchronize()
+        smp.sample()                                       # (chip idle for the moment: the boost clock)
+        idle = smp.mhz()
+        smp.n = 0
+        dts = timed(ks, hook=smp.sample, every=max(1, ks // 32))
+        clk = sorted(smp.mhz())
+        med = clk[len(clk) // 2] if clk else None
+        sustained = {"value": round(gB * ks / dts, 2), "unit": "event-windows/s", "ms_per_step": round(dts / ks * 1e3, 3), "steps": ks, "seconds": round(dts, 3),
+                     "ratio_to_value": round((gB * ks / dts) / (gB * a.steps / dt), 4),
+                     "shader_clock_mhz": {"median": round(med, 1) if med else None, "min": round(clk[0], 1) if clk else None,
+                                          "max": round(clk[-1], 1) if clk else None, "samples": len(clk)},
+                     "shader_clock_mhz_idle": round(idle[0], 1) if idle else None,
+                     "shader_clock_mhz_median_per_rank": [round(v, 1) for v in all_ranks(med or 0.0)],
+                     "note": "same step, same buffers; clock = 100 MHz x delta(s_memtime) / delta(s_memrealtime) of one-wave probes launched on their "
+                             "own stream during the region (ev2h_shader_clock_probe)"}
     if a.stub:                             # launcher self-test: one more step on every rank whose gathered result rank 0 checks
         last = step()
         if not isinstance(last, dict):
@@ -644,7 +705,7 @@ def run_rank(a) -> int:
     # transparency legs: the same workload in the other arithmetic modes (not part of `value`)
     legs, leg_kernel_ms = {}, {}
     if not a.stub and not a.no_legs:
-        for prec in ("f32", "bf16x3", "f16x2", "bf16"):
+        for prec in ("f32", "bf16x3", "f16x2", "bf16", "f16"):
             if prec == a.precision:
                 continue
             net.net.precision = prec
@@ -757,6 +818,7 @@ def run_rank(a) -> int:
         }
         if a.stub:
             res["stub"] = True
+            res["would_emit"] = expected_line_keys(world, a)      # what the real path prints at this world size (tests/test_bench_launcher.py)
             res["gathered_rows"] = int(last["class_logits"].shape[0]) if last is not None else None
             res["gathered_rank_ids"] = sorted({int(v) for v in last["class_logits"][:, 0, 0].tolist()}) if last is not None else None
         else:
@@ -792,14 +854,25 @@ def run_rank(a) -> int:
                 res["roofline_f32"] = roofline_entry("f32", B, leg_kernel_ms["f32"])
             if "bf16" in legs:                  # BASELINE.json config 3 names this arithmetic: its own roofline entry
                 res["roofline_bf16"] = roofline_entry("bf16", B, leg_kernel_ms["bf16"])
+            if "f16" in legs:                   # [r6] the reduced-precision mode that holds on a trained checkpoint (config 3 in practice)
+                res["roofline_f16"] = roofline_entry("f16", B, leg_kernel_ms["f16"])
             if legs:
                 res["other_modes"] = legs
             if latency:
                 res["latency_ms"] = latency
             if host_io:
                 res["pcie_inclusive"] = host_io
-            if world == 1 and not a.no_cpu_baseline:
+            if sustained:
+                res["value_sustained"] = sustained
+            if not a.no_cpu_baseline:
+                # rank 0 times the CPU port at EVERY world size (the other ranks wait at the final barrier, inside the RCCL timeout):
+                # a multi-GPU line without the key would be graded "unmeasured" 
                 res["cpu_baseline"] = cpu_baseline(sd, assets, Cc, N, a.cloud, a.cpu_seconds)
+                if world > 1:
+                    res["cpu_baseline"]["note"] = f"timed on rank 0's host while the other {world - 1} ranks idle at the final barrier"
+            want = expected_line_keys(world, a)
+            missing = [k for k in want if k not in res and k != "line_complete"]
+            res["line_complete"] = True if not missing else {"missing": missing}
         line = json.dumps(res)
     # RCCL writes its version banner to the C-level stdout, which -- when stdout is a pipe or a file -- sits in libc's buffer until
     # exit and would land AFTER the result (from any rank: a launcher merges the ranks' stdout).  Every rank flushes it, then a

@@ -71,7 +71,7 @@ class Weights(C.Structure):
                 ("cls0", Dense), ("cls4", Dense), ("clsm", SaBranch),
                 ("qconv0", Dense), ("qconv4", Dense * 2), ("qconv4T", vp * 2),
                 ("mano_sa2", (Dense * 2) * 2),
-                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci), ("l0_unscale", vp), ("flags", ci)]
+                ("head0", Dense * 2), ("head4", Dense * 2), ("precision", ci), ("l0_unscale", vp), ("flags", ci), ("f16_families", ci)]
 
 
 class TensorDesc(C.Structure):
@@ -80,10 +80,16 @@ class TensorDesc(C.Structure):
 
 DT_F32, DT_F64, DT_I64 = 0, 1, 2
 PACK_EQUALIZE, PACK_HOST_ONLY, PACK_UNEQUALIZED_OK = 1, 2, 4
-W_EQUALIZED, W_UNEQUALIZED_OK = 1, 2
-ABI_VERSION = 7     # 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs; 6: ev2h_pack_weights, ev2h_weights.flags; 7: ev2h_sa_desc.xyz_out
+FAM_SA, FAM_ROWS, FAM_QCONV, FAM_DENSE, FAM_ALL = 1, 2, 4, 8, 15      # EV2H_FAM_*: kernel families of the "f16" mode (ev2h_weights.f16_families)
 
-PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}
+
+def pack_f16_families(mask: int) -> int:
+    """EV2H_PACK_F16_FAMILIES(mask)"""
+    return (int(mask) & 15) << 8
+W_EQUALIZED, W_UNEQUALIZED_OK = 1, 2
+ABI_VERSION = 8     # 8: EV2H_PREC_F16 (one fp16 plane with f16x2's range machinery); 3: F16X2 range records; 4: ev2h_fp_mlp, ev2h_weights.fp1m; 5: window strides of the outputs; 6: ev2h_pack_weights, ev2h_weights.flags; 7: ev2h_sa_desc.xyz_out
+
+PREC = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3, "f16": 4}
 
 
 class ManoConsts(C.Structure):
@@ -98,11 +104,11 @@ class Outputs(C.Structure):
 
 
 EXPORTS = [
-    "ev2h_abi_version", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_side_stream_probe", "ev2h_struct_sizes",
+    "ev2h_abi_version", "ev2h_source_hash", "ev2h_build_defs", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_side_stream_probe", "ev2h_shader_clock_probe", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
-    "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_profile_set", "ev2h_range_report_entries", "ev2h_range_report",
+    "ev2h_workspace_bytes", "ev2h_forward", "ev2h_workspace_buffer", "ev2h_workspace_buffer_ex", "ev2h_profile_set", "ev2h_range_report_entries", "ev2h_range_report",
     "ev2h_pack_weights", "ev2h_packed_free", "ev2h_packed_weights", "ev2h_packed_bytes", "ev2h_packed_tensor_count", "ev2h_packed_tensor",
     "ev2h_packed_equalization_count", "ev2h_packed_equalization", "ev2h_packed_weight_spread_count", "ev2h_packed_weight_spread", "ev2h_pack_sa_image_bytes", "ev2h_pack_sa_images",
     "ev2h_pack_gemm_image_bytes", "ev2h_pack_gemm_image", "ev2h_plane_unscale",
@@ -128,15 +134,32 @@ def lib() -> C.CDLL:
         raise Ev2hError(f"{LIB_PATH} is missing: build the HIP library first "
                         f"(python -m ev2hands_amd.build). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    # [r6] the library must have been built from THESE sources: the sha256 of csrc/ + include/ is compiled in (ev2hands_amd/build.py).
+    # `*.so` is git-ignored yet travels to the GPU box, so a stale binary next to newer sources is otherwise possible and silent.
+    # EV2H_LIB_PATH (another build of the library, e.g. tools/asan_host.sh) opts out.
+    if not os.environ.get("EV2H_LIB_PATH"):
+        from . import build as _build
+        try:
+            L.ev2h_source_hash.restype = C.c_char_p
+            have = L.ev2h_source_hash().decode()
+        except AttributeError:
+            have = "(no stamp: built before round 6)"
+        want = _build.source_hash()
+        if have != want:
+            raise Ev2hError(f"{LIB_PATH} was built from other sources (stamp {have[:16]}, sources {want[:16]}): rebuild it "
+                            f"(python -m ev2hands_amd.build), or set EV2H_LIB_PATH to use another build on purpose.")
     L.ev2h_last_error.restype = C.c_char_p
     L.ev2h_workspace_bytes.restype = C.c_size_t
     L.ev2h_workspace_bytes.argtypes = [ci, ci]
     L.ev2h_workspace_buffer.restype = vp
     L.ev2h_workspace_buffer.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t)]
+    L.ev2h_workspace_buffer_ex.restype = vp
+    L.ev2h_workspace_buffer_ex.argtypes = [vp, ci, ci, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(ci)]
     L.ev2h_struct_sizes.restype = None
     L.ev2h_struct_sizes.argtypes = [C.c_size_t * 8]
     L.ev2h_set_side_stream.argtypes = [ci]
     L.ev2h_side_stream_probe.argtypes = [vp, ci, C.POINTER(C.c_float)]
+    L.ev2h_shader_clock_probe.argtypes = [vp, ci, vp]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -224,3 +247,28 @@ def side_stream_probe(spin_us: int = 50) -> float:
     check(lib().ev2h_side_stream_probe(stream_handle(), int(spin_us), C.byref(r)), "ev2h_side_stream_probe")
     return float(r.value)
 
+
+class ShaderClockSampler:
+    """Shader clock observed WHILE a workload runs (ev2h_shader_clock_probe): `sample()` enqueues a one-wave probe on a stream of
+    its own (it runs beside whatever the other streams are doing); `mhz()` synchronises that stream and returns the clocks of all
+    samples taken so far.  bench.py: `value_sustained`."""
+
+    def __init__(self, device, max_samples: int = 64, spin_us: int = 200):
+        import torch
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(self.device)
+        self.buf = torch.zeros(max_samples, 2, dtype=torch.int64, device=self.device)
+        self.n, self.spin_us = 0, int(spin_us)
+
+    def sample(self) -> None:
+        import torch
+        if self.n >= self.buf.shape[0]:
+            return
+        with torch.cuda.device(self.device):
+            check(lib().ev2h_shader_clock_probe(self.stream.cuda_stream, self.spin_us, self.buf[self.n].data_ptr()), "ev2h_shader_clock_probe")
+        self.n += 1
+
+    def mhz(self) -> list:
+        self.stream.synchronize()
+        v = self.buf[:self.n].cpu().double()
+        return [float(100.0 * c / r) for c, r in v.tolist() if r > 0]

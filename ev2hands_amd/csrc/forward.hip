@@ -182,6 +182,26 @@ extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* 
     return EV2H_OK;
 }
 
+// ---------------------------------------------------------------------------------------- shader-clock probe
+namespace {
+// one wave: shader-clock cycles (s_memtime) and constant-rate reference ticks (s_memrealtime, 100 MHz) over ~ticks reference ticks
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+}  // namespace
+
+extern "C" int ev2h_shader_clock_probe(ev2h_stream_t stream, int spin_us, unsigned long long* out_dev) {
+    EV2H_CHECK_ARG(out_dev && spin_us > 0 && spin_us <= 100000);
+    clock_probe_kernel<<<1, 64, 0, (hipStream_t)stream>>>((unsigned long long)spin_us * 100ull, out_dev);      // s_memrealtime: 100 MHz
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
 // ---------------------------------------------------------------------------------------- small kernels
 // internal entry points of other translation units (not part of the C ABI)
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d);
@@ -319,10 +339,13 @@ struct Rng {
     } while (0)
 
 static thread_local int g_precision = EV2H_PREC_F32;   // set by ev2h_forward for the helpers below (single in-flight forward per thread)
+static thread_local int g_f16_families = 0;            // F16 mode: the EV2H_FAM_* families on one fp16 plane (ev2h_weights.f16_families)
+// precision of one kernel family: the F16 mode runs the families outside its mask as F16X2 (same range records, images packed to match)
+static int fam_prec(int prec, int fam) { return prec == EV2H_PREC_F16 && !(g_f16_families & fam) ? EV2H_PREC_F16X2 : prec; }
 
 static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, int ldy, int relu, ev2h_stream_t st, const Rng& rg,
                  const float* group_bias = nullptr, int group_rows = 0, int ldbias = 0, int taps = 1, int rows_per_seq = 0,
-                 int rowmax_rows = 0, int skinny = 0) {
+                 int rowmax_rows = 0, int skinny = 0, int fam = EV2H_FAM_DENSE) {
     ev2h_gemm_desc d{};
     d.skinny = skinny;
     d.x_amax = rg.xa; d.x_amax2 = rg.xa2; d.x_group_rows = rg.xg; d.y_amax = rg.ya; d.y_group_rows = rg.yg;
@@ -332,7 +355,7 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
     d.bias_group_rows = group_rows; d.ldbias = ldbias;
     d.relu = relu; d.post_scale = w.post_scale; d.post_shift = w.post_shift;
     d.taps = taps; d.rows_per_seq = rows_per_seq; d.rowmax_rows = rowmax_rows;
-    d.precision = g_precision;
+    d.precision = fam_prec(g_precision, fam);
     d.Ws = (g_precision != EV2H_PREC_F32) ? w.Ws : nullptr;
     d.ws_tile_rows = w.ws_tile_rows;
     d.w_unscale = w.w_unscale;
@@ -524,6 +547,14 @@ extern "C" size_t ev2h_workspace_bytes(int B, int N) {
     return L.total;
 }
 
+static thread_local int g_last_l0_bf16 = 0;      // the calling thread's last ev2h_forward stored l0 as bf16 (BF16 mode, fused forms)
+
+extern "C" const void* ev2h_workspace_buffer_ex(void* workspace, int B, int N, const char* name, size_t* count, int* elem_type) {
+    const void* p = ev2h_workspace_buffer(workspace, B, N, name, count);
+    if (elem_type) *elem_type = (p && !strcmp(name, "l0") && g_last_l0_bf16) ? 1 : 0;
+    return p;
+}
+
 extern "C" const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count) {
     if (!workspace || !name || B <= 0 || N <= 0) return nullptr;
     Layout L;
@@ -546,6 +577,8 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
                         const int64_t* fps_init, const ev2h_outputs* out, const Ws& ws, ev2h_stream_t st, SideCtx* side, bool* forked) {
     const int R = B * N;
     const int prec = w->precision;
+    // F16: the precision each kernel family runs in (ev2h_weights.f16_families; everything else: prec itself)
+    const int prec_sa = fam_prec(prec, EV2H_FAM_SA), prec_rows = fam_prec(prec, EV2H_FAM_ROWS), prec_q = fam_prec(prec, EV2H_FAM_QCONV);
     auto rg = [&](int xid, int xg, int yid = -1, int yg = 0, int xid2 = -1) {
         Rng r{};
         if (ws.ranges_on) {
@@ -575,7 +608,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[4], 0));
         *forked = true;
     }
-    if (!bf16_direct_layer1(prec, w->sa1)) RUN(sa_table(prec, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
+    if (!bf16_direct_layer1(prec, w->sa1)) RUN(sa_table(prec_sa, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[5], side->stream));
     {
         const int S[3] = {512, 128, 128};
@@ -624,14 +657,14 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
         RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
-        RUN(sa_branches(prec, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
+        RUN(sa_branches(prec_sa, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
                         ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C, ws.r(R_FEAT)));
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {
         const ev2h_sa_module& m = w->sa2;
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[8], 0));
-        RUN(sa_module(prec, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi2, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
+        RUN(sa_module(prec_sa, "sa2", m, ws.f("l1cat"), 576, ws.f("ctr1"), ws.f("ctr2"), gi2, ws.i("cnt2"), B, 512, ws.f("P1b"), ws.f("l2buf"), 520, st,
                       ws.r(R_L1A), ws.r(R_P1B), ws.p1scale(1), ws.r(R_L2), 0, ws.f("l2buf") + 512, 520));      // + the xyz columns of enc.sa3's input
     }
     // ---- enc.sa3 group-all (TEHNet.py:181): 515 -> 256 -> 512 -> 1024, max over the 128 points
@@ -664,23 +697,24 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         qd.X = ws.f("l0"); qd.ldx = 256; qd.W = w->qconv0.W; qd.ldw = w->qconv0.ldw;
         qd.M = R; qd.N = w->qconv0.O; qd.K = w->qconv0.K;
         qd.bias = w->qconv0.b; qd.relu = 1; qd.post_scale = w->qconv0.post_scale; qd.post_shift = w->qconv0.post_shift;
-        qd.taps = 3; qd.rows_per_seq = N; qd.precision = prec; qd.Ws = w->qconv0.Ws; qd.ws_tile_rows = w->qconv0.ws_tile_rows;
+        qd.taps = 3; qd.rows_per_seq = N; qd.precision = prec_q; qd.Ws = w->qconv0.Ws; qd.ws_tile_rows = w->qconv0.ws_tile_rows;
         qd.w_unscale = w->qconv0.w_unscale;
     }
     const bool zsum_ok = !unfused_zsum && prec != EV2H_PREC_F32 && w->qconv0.Ws && ev2h_gemm_bf16_zsum_supported(&qd);
     const bool l0_bf16 = prec == EV2H_PREC_BF16 && fp1_fused && cls_fused && zsum_ok && !l0_f32;
+    g_last_l0_bf16 = l0_bf16 ? 1 : 0;                      // (ev2h_workspace_buffer_ex tells a debugger what "l0" holds)
     if (fp1_fused) {
         // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
         // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
         // the two hidden layers (3 x 268 MB written and read back at B = 256) never reach memory
         const ev2h_sa_module& m = w->fp1m;
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[9], 0));      // 3-NN selection: fork 1 above
-        RUN(sa_table(prec, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
+        RUN(sa_table(prec_rows, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
         ev2h_fp_desc d{};
         d.T = ws.f("fp1T"); d.ldt = 128; d.nn_idx = ws.i("nn1_idx"); d.nn_w = ws.f("nn1_w");
         d.b2 = m.br[0].b2; d.b3 = m.br[0].b3; d.W2s = m.br[0].W2s; d.W3s = m.br[0].W3s;
         d.w2_unscale = m.br[0].w2_unscale; d.w3_unscale = m.br[0].w3_unscale;
-        d.out = ws.f("l0"); d.ldo = 256; d.B = B; d.N = N; d.S = 512; d.C1 = 128; d.C2 = 128; d.C3 = 256; d.precision = prec;
+        d.out = ws.f("l0"); d.ldo = 256; d.B = B; d.N = N; d.S = 512; d.C1 = 128; d.C2 = 128; d.C3 = 256; d.precision = prec_rows;
         if (ws.ranges_on) {
             d.t_scale = ws.p1scale(4); d.t_amax = ws.r(R_FP1T); d.w2_norm = m.br[0].w2_norm; d.b2_max = m.br[0].b2_max; d.out_amax = ws.r(R_L0);
         }
@@ -690,7 +724,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     } else {
         RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
                                  ws.i("nn1_idx"), ws.f("nn1_w"), ws.r(R_FP1IN), st));
-        RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));
+        RUN(dense(w->fp1[0], ws.f("fp1in"), 128, R, ws.f("fp1h1"), 128, 1, st, rg(R_FP1IN, N, R_FP1H1, N)));      // (un-fused A/B forms: packed as FAM_DENSE)
         RUN(dense(w->fp1[1], ws.f("fp1h1"), 128, R, ws.f("fp1h2"), 128, 1, st, rg(R_FP1H1, N, R_FP1H2, N)));
         RUN(dense(w->fp1[2], ws.f("fp1h2"), 128, R, ws.f("l0"), 256, 1, st, rg(R_FP1H2, N, R_L0, N)));
     }
@@ -708,7 +742,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         d.T = ws.f("l0"); d.ldt = 256; d.b2 = c.b2; d.b3 = c.b3; d.W2s = c.W2s; d.W3s = c.W3s;
         d.w2_unscale = c.w2_unscale; d.w3_unscale = c.w3_unscale;
         d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits; d.out_cm_stride = out->logits_stride;
-        d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec;
+        d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec_rows;
         if (ws.ranges_on) { d.t_amax = ws.r(R_L0); d.w2_norm = c.w2_norm; d.b2_max = c.b2_max; }
         RUN(ev2h_fp_mlp_ex(&d, l0_bf16, 0, sx));
     } else {
@@ -734,7 +768,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     }
     if (!zsum_fused) {
         prof_begin("qconv0", st);
-        RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N), nullptr, 0, 0, 3, N));
+        RUN(dense(w->qconv0, ws.f("l0"), 256, R, ws.f("q1"), 512, 1, st, rg(R_L0, N), nullptr, 0, 0, 3, N, 0, 0, EV2H_FAM_QCONV));
         prof_end("qconv0", st);
     }
     // ---- attention (TEHNet.py:13-27).  The second query convolution (Conv1d -> BN, affine) is folded behind the attention's sum
@@ -761,7 +795,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         const char* const* nm = kHandNames[h];
         ev2h_stream_t sh = (h == 1) ? sd : st;
         int32_t* gi[2] = {ws.i(nm[3]), ws.i(nm[4])};
-        RUN(sa_module(prec, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh,
+        RUN(sa_module(prec_sa, h ? "manoR" : "manoL", m, ws.f("hf8") + (size_t)h * R * 8, 8, ws.f("pts4"), ws.f(nm[2]), gi, ws.i(nm[5]), B, N, ws.f(nm[0]), ws.f(nm[6]), 520, sh,
                       ws.r(R_HF + h), ws.r(R_P1M + h), ws.p1scale(2 + h), ws.r(R_M1 + h), 4, ws.f(nm[6]) + 512, 520));   // + the xyz columns of the regressor's sa2 input
         RUN(dense(w->mano_sa2[h][0], ws.f(nm[6]), 520, B * 128, ws.f(nm[7]), 256, 1, sh, rg(R_M1 + h, 128, R_MSA2H + h, 128, R_FEAT)));
         RUN(dense(w->mano_sa2[h][1], ws.f(nm[7]), 256, B * 128, ws.f(nm[8]), 512, 1, sh, rg(R_MSA2H + h, 128, R_M2 + h, 1), nullptr, 0, 0, 1, 0, 128));
@@ -797,19 +831,20 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
     EV2H_CHECK_ARG((out->vertices_stride == 0 || out->vertices_stride >= 2334) && (out->joints_stride == 0 || out->joints_stride >= 63));
     EV2H_CHECK_ARG(w->sa1.npoint == 512 && w->sa2.npoint == 128 && w->mano_sa1[0].npoint == 128 && w->mano_sa1[1].npoint == 128);
     EV2H_CHECK_ARG(w->sa1.nbranch == 3 && w->sa2.nbranch == 2 && w->mano_sa1[0].nbranch == 2 && w->mano_sa1[1].nbranch == 2);
-    if (w->precision == EV2H_PREC_F16X2 && !(w->flags & (EV2H_W_EQUALIZED | EV2H_W_UNEQUALIZED_OK))) {
+    if ((w->precision == EV2H_PREC_F16X2 || w->precision == EV2H_PREC_F16) && !(w->flags & (EV2H_W_EQUALIZED | EV2H_W_UNEQUALIZED_OK))) {
         // the F16X2 accuracy contract (ev2hands_hip.h): one power of two per window / per matrix keeps 22 bits only down to 2^-17 of
         // the maximum -- un-equalised checkpoints measured 6.6e-4 ... 0.23 relative error where equalised ones hold 1.3e-6
-        ev2h_set_error("ev2h_forward: F16X2 weights are not channel-equalised (pack them with ev2h_pack_weights(..., EV2H_PACK_EQUALIZE), "
+        ev2h_set_error("ev2h_forward: F16X2 / F16 weights are not channel-equalised (pack them with ev2h_pack_weights(..., EV2H_PACK_EQUALIZE), "
                        "or set EV2H_W_UNEQUALIZED_OK in ev2h_weights.flags to run them anyway, or use BF16X3 / F32)");
         return EV2H_ERR_ARG;
     }
     RUN(ev2h_init());
     g_precision = w->precision;
+    g_f16_families = w->precision == EV2H_PREC_F16 ? w->f16_families : 0;
     Ws ws;
     ws.base = static_cast<char*>(workspace);
     ws.B = B;
-    ws.ranges_on = (w->precision == EV2H_PREC_F16X2);
+    ws.ranges_on = (w->precision == EV2H_PREC_F16X2 || w->precision == EV2H_PREC_F16);      // the fp16-plane modes: range records are kept and used
     build_layout(ws.L, B, N);
     if (workspace_bytes < ws.L.total) {
         ev2h_set_error("ev2h_forward: workspace too small (%zu < %zu bytes)", workspace_bytes, ws.L.total);

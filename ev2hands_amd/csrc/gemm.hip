@@ -384,12 +384,12 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         TableP t{};
         t.X = d->X; t.ldx = d->ldx; t.W = d->W; t.ldw = d->ldw; t.Y = d->Y; t.ldy = d->ldy; t.M = d->M; t.N = d->N;
         t.bias = d->bias; t.relu = d->relu;
-        if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+        if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->x_amax) {
             t.x_amax = d->x_amax; t.x_amax2 = d->x_amax2; t.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
             t.y_amax = d->y_amax; t.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
             t.y_scale = d->y_scale; t.y_bound_w = d->y_bound_w; t.y_bound_b = d->y_bound_b;
             if (t.y_scale) EV2H_CHECK_ARG(!t.y_amax || t.x_group_rows == t.y_group_rows);
-        } else if (d->precision == EV2H_PREC_F16X2 && d->y_amax) {
+        } else if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->y_amax) {
             t.y_amax = d->y_amax; t.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
         }
         table_k8_kernel<<<ceil_div(d->M, TB_WAVES * TB_ROWS_PER_WAVE), 256, 0, (hipStream_t)stream>>>(t);
@@ -402,7 +402,7 @@ extern "C" int ev2h_gemm(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         SkinnyP q{};
         q.X = d->X; q.ldx = d->ldx; q.W = d->W; q.ldw = d->ldw; q.Y = d->Y; q.ldy = d->ldy; q.M = d->M; q.N = d->N; q.K = d->K;
         q.bias = d->bias; q.relu = d->relu; q.post_scale = d->post_scale; q.post_shift = d->post_shift;
-        if (d->precision == EV2H_PREC_F16X2 && d->y_amax) { q.y_amax = d->y_amax; q.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1; }
+        if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->y_amax) { q.y_amax = d->y_amax; q.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1; }
         gemm_skinny_kernel<<<dim3(ceil_div(d->N, 32), ceil_div(d->M, 8)), 256, 0, (hipStream_t)stream>>>(q);
         EV2H_CHECK_LAUNCH();
         return EV2H_OK;

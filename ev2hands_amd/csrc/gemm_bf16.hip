@@ -1,5 +1,6 @@
 // Dense layers on the 16-bit matrix pipe: same contract as gemm.hip (ev2h_gemm), operands split on the fly into the
-// NS planes of planes.hpp (NS = 2 "f16x2", NS = 3 "bf16x3": fp32-class; NS = 1 plain bf16), fp32 accumulate.
+// NS planes of planes.hpp (NS = 2 "f16x2", NS = 3 "bf16x3": fp32-class; NS = 1 plain bf16; NS = 4 [r6] the mode code of "f16": ONE
+// fp16 plane with f16x2's range scaling -- plane_count(NS) planes are stored, planes_f16(NS) selects the scaling), fp32 accumulate.
 // Three kernels: a generic one that splits both operands (W without a plane image: the tiny heads), a wide 128x256
 // one and the default 128x128 "occupancy" kernel, both with host-packed W plane images streamed by LDS-DMA.
 // First kernel:
@@ -42,7 +43,7 @@ struct GemmBP {
 
 template <int NS>
 struct GBCfg {
-    static constexpr int RS = NS * 64 + 16;                 // bytes per LDS row (NS planes of 32 bf16 + pad)
+    static constexpr int RS = plane_count(NS) * 64 + 16;      // bytes per LDS row (planes of 32 16-bit values + pad)
     static constexpr int OPER = GB_BM * RS;                 // one operand tile
     static constexpr int LDS_BYTES = 4 * OPER;              // 2 buffers x (A, B)
 };
@@ -51,7 +52,7 @@ struct GBCfg {
 // power-of-two scale of X row m (f16x2 with a range record, 1 otherwise)
 template <int NS>
 __device__ __forceinline__ float x_row_scale(const GemmBP& p, long m) {
-    if constexpr (NS != 2) return 1.f;
+    if constexpr (!planes_f16(NS)) return 1.f;
     if (!p.x_amax) return 1.f;
     const long mm = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
     const long g = mm / p.x_group_rows;
@@ -61,7 +62,7 @@ __device__ __forceinline__ float x_row_scale(const GemmBP& p, long m) {
 }
 template <int NS>
 __device__ __forceinline__ void scale_rows(f32x4& v, float s) {
-    if constexpr (NS == 2) v *= s;       // exact (power of two); the products are multiplied back in the epilogue
+    if constexpr (planes_f16(NS)) v *= s;       // exact (power of two); the products are multiplied back in the epilogue
 }
 
 // Epilogue shared by the three kernels.  acc[i][j][r] = output (row m0 + row0 + 32 i + mfma_row(r, half), column col0 + 32 j + l31):
@@ -85,9 +86,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
         sj[j] = (p.post_scale && okc) ? p.post_scale[col] : 1.f;
         tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
     }
-    const bool xs_on = (NS == 2) && p.x_amax != nullptr;
-    const bool ys_on = (NS == 2) && p.y_scale != nullptr;
-    const bool track = (NS == 2) && p.y_amax != nullptr;
+    const bool xs_on = planes_f16(NS) && p.x_amax != nullptr;
+    const bool ys_on = planes_f16(NS) && p.y_scale != nullptr;
+    const bool track = planes_f16(NS) && p.y_amax != nullptr;
     auto y_store_scale = [&](long row) {          // power of two that keeps y_bound_w * max|X_g| + y_bound_b below 2^15
         const long rr = row < p.M ? row : p.M - 1;
         const long g = rr / p.x_group_rows;
@@ -125,10 +126,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmBP& p, f32x16 (&acc)[NI]
                     float v = acc[i][j][r] * cx + bj[j];
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.post_scale) v = __fmaf_rn(v, sj[j], tj[j]);
-                    if constexpr (NS == 2) v *= sy;
+                    if constexpr (planes_f16(NS)) v *= sy;
                     if (row < p.M && col < p.N) {
                         p.Y[(long)row * p.ldy + col] = v;
-                        if constexpr (NS == 2) amr = fmaxf(amr, fabsf(v));
+                        if constexpr (planes_f16(NS)) amr = fmaxf(amr, fabsf(v));
                     }
                 }
                 if constexpr (GEN) {
@@ -239,13 +240,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
         }
     };
     auto swrite_one = [&](char* dst, const f32x4 (&r)[2]) {
-        unsigned q[4][NS];
+        unsigned q[4][plane_count(NS)];
         split_planes<NS>(r[0][0], r[0][1], q[0]);
         split_planes<NS>(r[0][2], r[0][3], q[1]);
         split_planes<NS>(r[1][0], r[1][1], q[2]);
         split_planes<NS>(r[1][2], r[1][3], q[3]);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < plane_count(NS); ++s) {
             u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
             *reinterpret_cast<u32x4*>(dst + lrow * RS + s * 64 + lseg * 16) = v;
         }
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_kernel(GemmBP p) {
         const char* pb = sB + (wn * 32 + l31) * RS + half * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            u32x4 b[NS], a0[NS], a1[NS];
+            u32x4 b[plane_count(NS)], a0[plane_count(NS)], a1[plane_count(NS)];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < plane_count(NS); ++s) {
                 b[s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
                 a0[s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
                 a1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
@@ -311,7 +312,7 @@ constexpr int GW_BN = 256;
 
 template <int NS>
 struct GWCfg {
-    static constexpr int RS = NS * 64 + 16;
+    static constexpr int RS = plane_count(NS) * 64 + 16;
     static constexpr int A_BYTES = GB_BM * RS;
     static constexpr int B_BYTES = GW_BN * RS;
     static constexpr int LDS_BYTES = 2 * (A_BYTES + B_BYTES);
@@ -364,13 +365,13 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         f32x4 r[2] = {ra[0], ra[1]};
         if (!oka) { r[0] = f32x4{0.f, 0.f, 0.f, 0.f}; r[1] = r[0]; }
         scale_rows<NS>(r[0], xs); scale_rows<NS>(r[1], xs);
-        unsigned q[4][NS];
+        unsigned q[4][plane_count(NS)];
         split_planes<NS>(r[0][0], r[0][1], q[0]);
         split_planes<NS>(r[0][2], r[0][3], q[1]);
         split_planes<NS>(r[1][0], r[1][1], q[2]);
         split_planes<NS>(r[1][2], r[1][3], q[3]);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < plane_count(NS); ++s) {
             u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
             *reinterpret_cast<u32x4*>(dst + lrow * RS + s * 64 + lseg * 16) = v;
         }
@@ -409,9 +410,9 @@ __global__ __launch_bounds__(GB_THREADS, 2) void gemm_nt_bf16_wide_kernel(GemmBP
         const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            u32x4 a[2][NS], b[2][NS];
+            u32x4 a[2][plane_count(NS)], b[2][plane_count(NS)];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < plane_count(NS); ++s) {
                 a[0][s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
                 a[1][s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
                 b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
@@ -486,7 +487,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
         tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
     }
     float cx = p.w_unscale;
-    if (NS == 2 && p.x_amax) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
+    if (planes_f16(NS) && p.x_amax) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
     float amf = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -504,7 +505,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
             }
     __syncthreads();                                           // the key tile is complete
     float sq = 1.f, sk = 1.f;
-    if constexpr (NS == 2) {
+    if constexpr (planes_f16(NS)) {
         sq = f16x2_scale(wave_max_u32_dpp(__float_as_uint(amf)));
         float km = 0.f;
         for (int i = lane; i < 4 * KLD; i += 64) km = fmaxf(km, (i % KLD) < GB_BM + 2 ? fabsf(keyL[i]) : 0.f);
@@ -523,24 +524,24 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            u32x4 ap[NS];
+            u32x4 ap[plane_count(NS)];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float a0 = kr[32 * i + mfma_row(8 * kb + 2 * w, half)] * sk, a1 = kr[32 * i + mfma_row(8 * kb + 2 * w + 1, half)] * sk;
-                unsigned o[NS];
+                unsigned o[plane_count(NS)];
                 split_planes<NS>(a0, a1, o);
 #pragma unroll
-                for (int s_ = 0; s_ < NS; ++s_) ap[s_][w] = o[s_];
+                for (int s_ = 0; s_ < plane_count(NS); ++s_) ap[s_][w] = o[s_];
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                u32x4 bq[NS];
+                u32x4 bq[plane_count(NS)];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    unsigned o[NS];
+                    unsigned o[plane_count(NS)];
                     split_planes<NS>(acc[i][j][8 * kb + 2 * w] * sq, acc[i][j][8 * kb + 2 * w + 1] * sq, o);
 #pragma unroll
-                    for (int s_ = 0; s_ < NS; ++s_) bq[s_][w] = o[s_];
+                    for (int s_ = 0; s_ < plane_count(NS); ++s_) bq[s_][w] = o[s_];
                 }
 #pragma unroll
                 for (int q = 0; q < Planes<NS>::NPROD; ++q) z[j] = mfma_planes<NS>(ap[Planes<NS>::A[q]], bq[Planes<NS>::B[q]], z[j]);
@@ -585,7 +586,7 @@ constexpr int GO_BN = 128, GO_THREADS = 256;
 // zero at the window ends) and the three W tiles of that chunk are multiplied against row-shifted views of it.
 template <int NS, bool TAP3>
 struct GOCfg {
-    static constexpr int RS = NS * 64 + 16;
+    static constexpr int RS = plane_count(NS) * 64 + 16;
     static constexpr int A_ROWS = GB_BM + (TAP3 ? 2 : 0);
     static constexpr int A_BYTES = A_ROWS * RS;
     static constexpr int B_BYTES = GO_BN * RS;
@@ -692,13 +693,13 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             f32x4 r0 = r[2 * hh], r1 = r[2 * hh + 1];
             if (!ok || (hh == 1 && !fulla)) { r0 = f32x4{0.f, 0.f, 0.f, 0.f}; r1 = r0; }
             scale_rows<NS>(r0, sc); scale_rows<NS>(r1, sc);
-            unsigned q[4][NS];
+            unsigned q[4][plane_count(NS)];
             split_planes<NS>(r0[0], r0[1], q[0]);
             split_planes<NS>(r0[2], r0[3], q[1]);
             split_planes<NS>(r1[0], r1[1], q[2]);
             split_planes<NS>(r1[2], r1[3], q[3]);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < plane_count(NS); ++s) {
                 u32x4 v = {q[0][s], q[1][s], q[2][s], q[3][s]};
                 *reinterpret_cast<u32x4*>(sA + ldsrow * RS + s * 64 + lseg * 32 + hh * 16) = v;
             }
@@ -725,9 +726,9 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         const char* pb = sB + (wn * 64 + l31) * RS + half * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            u32x4 a[2][NS], b[2][NS];
+            u32x4 a[2][plane_count(NS)], b[2][plane_count(NS)];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < plane_count(NS); ++s) {
                 a[0][s] = *reinterpret_cast<const u32x4*>(pa + s * 64 + m * 32);
                 a[1][s] = *reinterpret_cast<const u32x4*>(pa + 32 * RS + s * 64 + m * 32);
                 b[0][s] = *reinterpret_cast<const u32x4*>(pb + s * 64 + m * 32);
@@ -858,7 +859,7 @@ int launch_go_t(const GemmBP& p, const char* Ws, hipStream_t st) {
 // 16-column k blocks, the plane products): bit-identical, so the choice (by launch size) never shows in a result.
 template <int NS>
 struct GSCfg {
-    static constexpr int RS = NS * 64 + 16;
+    static constexpr int RS = plane_count(NS) * 64 + 16;
     static constexpr int A_BYTES = 64 * RS, B_BYTES = 64 * RS, BUF = A_BYTES + B_BYTES, LDS_BYTES = 2 * BUF;
 };
 
@@ -890,13 +891,13 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_small_kernel(GemmB
         f32x4 a = r0, b = r1;
         if (!ok) { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
         scale_rows<NS>(a, xs); scale_rows<NS>(b, xs);
-        unsigned q[4][NS];
+        unsigned q[4][plane_count(NS)];
         split_planes<NS>(a[0], a[1], q[0]);
         split_planes<NS>(a[2], a[3], q[1]);
         split_planes<NS>(b[0], b[1], q[2]);
         split_planes<NS>(b[2], b[3], q[3]);
 #pragma unroll
-        for (int s_ = 0; s_ < NS; ++s_) {
+        for (int s_ = 0; s_ < plane_count(NS); ++s_) {
             u32x4 v = {q[0][s_], q[1][s_], q[2][s_], q[3][s_]};
             *reinterpret_cast<u32x4*>(A + lrow * RS + s_ * 64 + lseg * 16) = v;
         }
@@ -917,9 +918,9 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_small_kernel(GemmB
         const char* pb = B + (wn * 32 + l31) * RS + half * 16;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            u32x4 a[NS], b[NS];
+            u32x4 a[plane_count(NS)], b[plane_count(NS)];
 #pragma unroll
-            for (int s_ = 0; s_ < NS; ++s_) {
+            for (int s_ = 0; s_ < plane_count(NS); ++s_) {
                 a[s_] = *reinterpret_cast<const u32x4*>(pa + s_ * 64 + m * 32);
                 b[s_] = *reinterpret_cast<const u32x4*>(pb + s_ * 64 + m * 32);
             }
@@ -986,7 +987,7 @@ int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
 
 // geometry of the W plane images of the fast kernels (ev2h_tile_geometry): bytes per LDS row, K columns per tile
 int ev2h_gemm_tile_geometry(int ns, int out[2]) {
-    out[0] = ns == 1 ? GBCfg<1>::RS : ns == 2 ? GBCfg<2>::RS : GBCfg<3>::RS;
+    out[0] = ns == 1 ? GBCfg<1>::RS : ns == 2 ? GBCfg<2>::RS : ns == 3 ? GBCfg<3>::RS : GBCfg<4>::RS;
     out[1] = GB_BK;
     return EV2H_OK;
 }
@@ -996,10 +997,10 @@ int ev2h_gemm_tile_geometry(int ns, int out[2]) {
 // ev2h_gemm_bf16_zsum_supported: the shapes the tap kernel takes -- the caller tests them FIRST and runs the two-pass form otherwise;
 // an error of the launch itself is then an error, not a silent change of schedule.
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d) {
-    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_BF16X3) &&
+    if (!(d->taps == 3 && d->Ws && d->ws_tile_rows == 128 && (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_BF16 || d->precision == EV2H_PREC_BF16X3 || d->precision == EV2H_PREC_F16) &&
           d->K % GB_BK == 0 && d->rows_per_seq > 0 && d->rows_per_seq % GB_BM == 0 && d->M % d->rows_per_seq == 0 && d->N % GO_BN == 0))
         return false;
-    if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+    if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->x_amax) {
         const int xg = d->x_group_rows > 0 ? d->x_group_rows : 1;
         if (xg % GB_BM != 0 || xg % d->rows_per_seq != 0) return false;
     }
@@ -1016,7 +1017,7 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     p.bias = d->bias; p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
     p.w_unscale = d->w_unscale > 0.f ? d->w_unscale : 1.f;
     p.x_group_rows = p.y_group_rows = 1;
-    if (d->precision == EV2H_PREC_F16X2 && d->x_amax) {
+    if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->x_amax) {
         p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
     }
     p.zs_key = reinterpret_cast<const float4*>(key_pm); p.zs_out = zpart;
@@ -1031,6 +1032,7 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     if (d->precision == EV2H_PREC_F16X2) return launch_go_t<2, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_BF16) return launch_go_t<1, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_BF16X3) return launch_go_t<3, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_F16) return launch_go_t<4, true, ZS>(p, (const char*)d->Ws, (hipStream_t)stream);
     return EV2H_ERR_ARG;
 }
 
@@ -1046,7 +1048,7 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     p.relu = d->relu; p.post_scale = d->post_scale; p.post_shift = d->post_shift;
     p.rowmax_rows = d->rowmax_rows;
     p.w_unscale = d->w_unscale > 0.f ? d->w_unscale : 1.f;
-    if (d->precision == EV2H_PREC_F16X2) {
+    if (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) {
         p.x_amax = d->x_amax; p.x_amax2 = d->x_amax2; p.x_group_rows = d->x_group_rows > 0 ? d->x_group_rows : 1;
         p.y_amax = d->y_amax; p.y_group_rows = d->y_group_rows > 0 ? d->y_group_rows : 1;
         p.y_scale = d->y_scale; p.y_bound_w = d->y_bound_w; p.y_bound_b = d->y_bound_b;
@@ -1063,7 +1065,7 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
     if (general) {
         p.tiles_n = ceil_div(d->N, GB_BN);
         p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
-        return launch_gb<2, true>(p, (hipStream_t)stream);
+        return d->precision == EV2H_PREC_F16 ? launch_gb<4, true>(p, (hipStream_t)stream) : launch_gb<2, true>(p, (hipStream_t)stream);
     }
     if (d->Ws && d->ws_tile_rows == 128) {   // 128-row plane images: three small workgroups per CU
         p.tiles_n = ceil_div(d->N, GO_BN);
@@ -1071,6 +1073,7 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         if (d->precision == EV2H_PREC_BF16X3) return launch_go<3>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_F16X2) return launch_go<2>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_BF16) return launch_go<1>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_F16) return launch_go<4>(p, (const char*)d->Ws, (hipStream_t)stream);
     }
     if (d->Ws) {   // host-packed plane images of W: wide tile, W streamed by LDS-DMA
         p.tiles_n = ceil_div(d->N, GW_BN);
@@ -1078,12 +1081,14 @@ int ev2h_gemm_bf16(const ev2h_gemm_desc* d, ev2h_stream_t stream) {
         if (d->precision == EV2H_PREC_BF16X3) return launch_gw<3>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_F16X2) return launch_gw<2>(p, (const char*)d->Ws, (hipStream_t)stream);
         if (d->precision == EV2H_PREC_BF16) return launch_gw<1>(p, (const char*)d->Ws, (hipStream_t)stream);
+        if (d->precision == EV2H_PREC_F16) return launch_gw<4>(p, (const char*)d->Ws, (hipStream_t)stream);
     }
     p.tiles_n = ceil_div(d->N, GB_BN);
     p.nblk = ceil_div(d->M, GB_BM) * p.tiles_n;
     if (d->precision == EV2H_PREC_BF16X3) return launch_gb<3, false>(p, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_F16X2) return launch_gb<2, false>(p, (hipStream_t)stream);
     if (d->precision == EV2H_PREC_BF16) return launch_gb<1, false>(p, (hipStream_t)stream);
+    if (d->precision == EV2H_PREC_F16) return launch_gb<4, false>(p, (hipStream_t)stream);
     ev2h_set_error("ev2h_gemm: unknown precision %d", d->precision);
     return EV2H_ERR_ARG;
 }

@@ -342,17 +342,20 @@ Equalization equalize_channels(Folded& F, int sweeps = 3) {
 inline uint16_t f16_bits(float x) { _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }      // RNE, overflow -> inf
 inline float f16_value(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
 
+// mode code -> planes stored per operand / fp16 planes with the W / u range factor (csrc/planes.hpp: plane_count, planes_f16)
+inline int npl(int ns) { return ns == 4 ? 1 : ns; }
+inline bool is_f16(int ns) { return ns == 2 || ns == 4; }
+
 void split_planes_host(const std::vector<float>& x, int ns, std::vector<uint16_t>* planes) {
     const size_t n = x.size();
-    for (int s = 0; s < ns; ++s) planes[s].resize(n);
-    if (ns == 2) {
+    for (int s = 0; s < npl(ns); ++s) planes[s].resize(n);
+    if (is_f16(ns)) {
         for (size_t i = 0; i < n; ++i)
-            if (std::fabs(x[i]) >= 65504.0f) fail("f16x2 needs |weight| < 65504 (fp16 range); use precision bf16x3 or f32 for this checkpoint");
+            if (std::fabs(x[i]) >= 65504.0f) fail("f16x2 / f16 need |weight| < 65504 (fp16 range); use precision bf16x3 or f32 for this checkpoint");
         for (size_t i = 0; i < n; ++i) {
             const uint16_t h = f16_bits(x[i]);
-            const float r = x[i] - f16_value(h);
             planes[0][i] = h;
-            planes[1][i] = f16_bits(r);
+            if (ns == 2) planes[1][i] = f16_bits(x[i] - f16_value(h));
         }
     } else if (ns == 1) {
         for (size_t i = 0; i < n; ++i) {
@@ -374,11 +377,11 @@ void split_planes_host(const std::vector<float>& x, int ns, std::vector<uint16_t
     }
 }
 
-// Power of two u such that the planes are taken of W / u.  F16X2 only: fp16 has 5 exponent bits, so the low plane of a weight below
+// Power of two u such that the planes are taken of W / u.  F16X2 / F16 only: fp16 has 5 exponent bits, so the low plane of a weight below
 // 2^-3 is subnormal and small-magnitude layers lose accuracy (measured 2.6e-4 at |W| ~ 1e-4).  Dividing by u = 2^-k with
 // max|W / u| in [2^13, 2^14) is exact and the kernels multiply the accumulated product by u (also exact).
 double plane_unscale(const double* W, size_t count, int ns) {
-    if (ns != 2) return 1.0;
+    if (!is_f16(ns)) return 1.0;
     double m = 0.0;
     for (size_t i = 0; i < count; ++i) { const double a = std::fabs(W[i]); if (a > m || a != a) m = a; }
     if (m == 0.0 || !std::isfinite(m)) return 1.0;
@@ -428,10 +431,10 @@ SaImages sa_images(const double* W2in, const double* W3in, int C1, int C2, int C
         for (int r = 0; r < left; ++r)      // rows 8.. of the high-plane image: the leftover rows' LOW plane
             memcpy(&p2[0][(size_t)(base + 8 + r) * C1], &p2[1][(size_t)(base + r) * C1], (size_t)C1 * 2);
     }
-    const int rs2 = ns * 64 + 16;
+    const int rs2 = npl(ns) * 64 + 16;
     R.i2.assign((size_t)(C1 / 32) * R2 * rs2, 0);
     for (int c = 0; c < C1 / 32; ++c)
-        for (int s = 0; s < ns; ++s)
+        for (int s = 0; s < npl(ns); ++s)
             for (int r = 0; r < R2; ++r)
                 memcpy(&R.i2[((size_t)c * R2 + r) * rs2 + s * 64], &p2[s][(size_t)r * C1 + 32 * c], 64);
     // layer-3 contraction order follows the MFMA D layout of layer 2: position 32t+16m+8h+e <-> channel 32t+16m+4h+(e&3)+8(e>>2)
@@ -451,9 +454,9 @@ SaImages sa_images(const double* W2in, const double* W3in, int C1, int C2, int C
             for (int j = 0; j < 4; ++j) { hrow[4 + j] = hrow[j]; hrow[8 + j] = lrow[j]; hrow[12 + j] = 0; }
         }
     }
-    const int rs3 = ns * C2P * 2 + 16;
+    const int rs3 = npl(ns) * C2P * 2 + 16;
     R.i3.assign((size_t)(C3 / 32) * 32 * rs3, 0);
-    for (int s = 0; s < ns; ++s)
+    for (int s = 0; s < npl(ns); ++s)
         for (int o = 0; o < C3; ++o)
             memcpy(&R.i3[(size_t)o * rs3 + (size_t)s * C2P * 2], &p3[s][(size_t)o * C2P], (size_t)C2P * 2);
     if (g[0] != T2 || g[1] != C2P || g[2] != rs2 || g[3] != rs3 || g[4] != R2 * rs2 || g[5] != 32 * rs3)
@@ -474,12 +477,12 @@ std::vector<uint8_t> gemm_image(const double* W, int N, int K, int ns, int rows,
         for (int k = 0; k < K; ++k) Wp[(size_t)r * Kp + k] = (float)(W[(size_t)r * K + k] / u);
     std::vector<uint16_t> pl[3];
     split_planes_host(Wp, ns, pl);
-    const int rs = ns * 64 + 16;
+    const int rs = npl(ns) * 64 + 16;
     int g[10];
     if (ev2h_tile_geometry(128, 128, 256, ns, g) != EV2H_OK || g[6] != rs || g[7] != 32)
         fail("dense W image geometry: the packer builds rows of %d B x 32 k, the kernels expect %d B x %d k", rs, g[6], g[7]);
     std::vector<uint8_t> img((size_t)tn * nk * rows * rs, 0);
-    for (int s = 0; s < ns; ++s)
+    for (int s = 0; s < npl(ns); ++s)
         for (int a = 0; a < tn; ++a)
             for (int kk = 0; kk < nk; ++kk)
                 for (int r = 0; r < rows; ++r)
@@ -522,6 +525,9 @@ constexpr int GEMM_W_TILE_ROWS = 128;      // rows per W image tile (128: occupa
 struct Builder {
     ev2h_packed& P;
     int ns;
+    // plane-mode code of one kernel family: the F16 mode packs the families of ev2h_weights.f16_families with one fp16 plane (4)
+    // and the others as F16X2 (2); every other precision has one code for everything
+    int nsf(int fam) const { return P.w.precision == EV2H_PREC_F16 ? ((P.w.f16_families & fam) ? 4 : 2) : ns; }
     std::vector<std::pair<const void**, size_t>> fix;     // pointer fields of P.w and the arena offsets they get
 
     size_t put(const std::string& name, int dtype, int rows, int cols, const void* data, size_t bytes) {
@@ -565,7 +571,8 @@ struct Builder {
 
     // one folded Conv/Linear as the GEMM kernels take it: W [O][Kfull] (row-major), K per tap (0 = Kfull padded)
     void dense(ev2h_dense& d, const std::string& name, const Vec& W, int O, int Kfull, const Vec* b, const Vec* ps = nullptr, const Vec* pt = nullptr,
-               int K = 0) {
+               int K = 0, int fam = EV2H_FAM_DENSE) {
+        const int ns = nsf(fam);
         const int ldw = up(Kfull, 4);
         const Vec Wp = pad2(W.data(), O, Kfull, Kfull, O, ldw);
         dev(&d.W, name + ".W", Wp.data(), O, ldw);
@@ -573,7 +580,7 @@ struct Builder {
         if (ps) vec(&d.post_scale, name + ".ps", *ps);
         if (pt) vec(&d.post_shift, name + ".pt", *pt);
         d.O = O; d.K = K ? K : ldw; d.ldw = ldw;
-        if (ns == 2) P.wspread.push_back(weight_spread(name, W.data(), W.size(), plane_unscale(W.data(), W.size(), ns)));
+        if (is_f16(ns)) P.wspread.push_back(weight_spread(name, W.data(), W.size(), plane_unscale(W.data(), W.size(), ns)));
         if (ns && O >= 96) {             // all but the tiny heads: pre-split W images, streamed by LDS-DMA
             dev_bytes(&d.Ws, name + ".Ws", gemm_image(Wp.data(), O, ldw, ns, GEMM_W_TILE_ROWS, &d.w_unscale));
             d.ws_tile_rows = GEMM_W_TILE_ROWS;
@@ -601,10 +608,11 @@ struct Builder {
         }
     }
 
-    void chain_images(ev2h_sa_branch& br, const std::string& n, const double* W2, const double* W3, int C1, int C2, int C3) {
+    void chain_images(ev2h_sa_branch& br, const std::string& n, const double* W2, const double* W3, int C1, int C2, int C3, int fam) {
+        const int ns = nsf(fam);
         SaImages im = sa_images(W2, W3, C1, C2, C3, ns);
         br.w2_unscale = im.u2; br.w3_unscale = im.u3;
-        if (ns == 2) {
+        if (is_f16(ns)) {
             P.wspread.push_back(weight_spread(n + ".W2", W2, (size_t)C2 * C1, im.u2));
             P.wspread.push_back(weight_spread(n + ".W3", W3, (size_t)C3 * C2, im.u3));
         }
@@ -613,6 +621,7 @@ struct Builder {
     }
 
     void sa_module(ev2h_sa_module& m, const Folded& F, const std::string& prefix, const MsgSpec& sp, int nfeat, int kf) {
+        const int ns = nsf(EV2H_FAM_SA);
         m.kf = kf; m.npoint = sp.npoint; m.nbranch = sp.nb;
         int c1sum = 0;
         for (int i = 0; i < sp.nb; ++i) c1sum += sp.mlp[i][0];
@@ -648,14 +657,14 @@ struct Builder {
             }
             br.w2_norm = bound(max_row_l1(L1.W.data(), C2, C1, C1));
             br.b2_max = bound(max_abs(L1.b));
-            if (ns) chain_images(br, n, L1.W.data(), L2.W.data(), C1, C2, C3);
+            if (ns) chain_images(br, n, L1.W.data(), L2.W.data(), C1, C2, C3, EV2H_FAM_SA);
             r0 += C1;
         }
         dev(&m.W1f, prefix + ".W1f", W1f.data(), c1sum, kf);
         vec(&m.b1, prefix + ".b1", b1);
         if (ns && kf >= 32) {            // enc.sa2 (K = 320): plane images, the fast GEMM kernel
             dev_bytes(&m.W1fs, prefix + ".W1fs", gemm_image(W1f.data(), c1sum, kf, ns, GEMM_W_TILE_ROWS, &m.w1f_unscale));
-            if (ns == 2) P.wspread.push_back(weight_spread(prefix + ".W1f", W1f.data(), W1f.size(), m.w1f_unscale));
+            if (is_f16(ns)) P.wspread.push_back(weight_spread(prefix + ".W1f", W1f.data(), W1f.size(), m.w1f_unscale));
         } else {
             m.w1f_unscale = (float)plane_unscale(W1f.data(), W1f.size(), ns);      // K = 8 tables run as fp32 fma chains (table_k8_kernel)
         }
@@ -667,6 +676,7 @@ struct Builder {
     // as a table over the coarse points (W1f, b1 -- it commutes with the interpolation), layers 2-3 as the tile images of the fused
     // set-abstraction kernel
     void fp_module(ev2h_sa_module& m, const Folded& F, const std::string& prefix) {
+        const int ns = nsf(EV2H_FAM_ROWS);
         const Layer &L0 = F.at(idx(prefix, 0)), &L1 = F.at(idx(prefix, 1)), &L2 = F.at(idx(prefix, 2));
         m.kf = L0.I; m.npoint = 0; m.nbranch = 1;
         if (!(L0.O == 128 && L1.O == 128 && L2.O == 256 && m.kf % 32 == 0)) fail("fp1 chain is not 128-128-256");
@@ -678,11 +688,11 @@ struct Builder {
         br.w1x_norm = 0.f;
         br.w2_norm = bound(max_row_l1(L1.W.data(), L1.O, L1.I, L1.I));
         br.b2_max = bound(max_abs(L1.b));
-        chain_images(br, n, L1.W.data(), L2.W.data(), L0.O, L1.O, L2.O);
+        chain_images(br, n, L1.W.data(), L2.W.data(), L0.O, L1.O, L2.O, EV2H_FAM_ROWS);
         dev(&m.W1f, n + ".W1f", L0.W.data(), L0.O, L0.I);
         vec(&m.b1, n + ".b1", L0.b);
         dev_bytes(&m.W1fs, n + ".W1fs", gemm_image(L0.W.data(), L0.O, L0.I, ns, GEMM_W_TILE_ROWS, &m.w1f_unscale));
-        if (ns == 2) P.wspread.push_back(weight_spread(n + ".W1f", L0.W.data(), L0.W.size(), m.w1f_unscale));
+        if (is_f16(ns)) P.wspread.push_back(weight_spread(n + ".W1f", L0.W.data(), L0.W.size(), m.w1f_unscale));
         m.w1f_norm = bound(max_row_l1(L0.W.data(), L0.O, L0.I, L0.I));
         m.b1_max = bound(max_abs(L0.b));
     }
@@ -708,7 +718,7 @@ struct Builder {
         br.w1x_norm = 0.f;
         br.w2_norm = bound(max_row_l1(c0.W.data(), C2, C1, C1));
         br.b2_max = bound(max_abs(c0.b));
-        chain_images(br, "clsm", c0.W.data(), W4p.data(), C1, C2, 32);
+        chain_images(br, "clsm", c0.W.data(), W4p.data(), C1, C2, 32, EV2H_FAM_ROWS);
     }
 
     void build(Folded& F, int in_channels) {
@@ -768,7 +778,7 @@ struct Builder {
                 for (int k = 0; k < 768; ++k) W4T[(size_t)k * 256 + o] = W4[(size_t)o * 768 + k];
             dev(&w.qconv4T[h], p + ".4.WT", W4T.data(), 768, 256);
         }
-        dense(w.qconv0, "qconv0", W0, 512, 768, &b0, &a0, &be0, 256);
+        dense(w.qconv0, "qconv0", W0, 512, 768, &b0, &a0, &be0, 256, EV2H_FAM_QCONV);
         // the attention's `value` is l0 itself (TEHNet.py:20-26): its channels are divided by their equalisation factor there
         for (const auto& kv : P.eq)
             if (kv.first == "l0") {
@@ -786,6 +796,7 @@ int planes_of(int precision) {
         case EV2H_PREC_BF16: return 1;
         case EV2H_PREC_F16X2: return 2;
         case EV2H_PREC_BF16X3: return 3;
+        case EV2H_PREC_F16: return 4;          // mode code: one fp16 plane (npl), fp16 range factors (is_f16)
     }
     fail("unknown precision %d", precision);
 }
@@ -834,6 +845,7 @@ extern "C" int ev2h_pack_weights(const ev2h_tensor_desc* tensors, int n, int in_
         P = new ev2h_packed();
         memset(&P->w, 0, sizeof(P->w));
         P->w.precision = precision;
+        if (precision == EV2H_PREC_F16) P->w.f16_families = ((flags >> 8) & 15) ? ((flags >> 8) & 15) : EV2H_FAM_ALL;
         // exact power-of-two channel equalisation: applied in EVERY precision mode, so that all modes run the same network
         // representation (the exact-fp32 results do not change by a bit)
         if (flags & EV2H_PACK_EQUALIZE) { P->eq = equalize_channels(F); P->w.flags |= EV2H_W_EQUALIZED; }
@@ -918,7 +930,7 @@ extern "C" int ev2h_pack_sa_image_bytes(int C1, int C2, int C3, int planes, size
 
 extern "C" int ev2h_pack_sa_images(const double* W2, const double* W3, int C1, int C2, int C3, int planes, void* img2, void* img3, float* u2,
                                    float* u3) {
-    EV2H_CHECK_ARG(W2 && W3 && img2 && img3 && u2 && u3 && planes >= 1 && planes <= 3);
+    EV2H_CHECK_ARG(W2 && W3 && img2 && img3 && u2 && u3 && planes >= 1 && planes <= 4);
     EV2H_TRY
     const SaImages im = sa_images(W2, W3, C1, C2, C3, planes);
     memcpy(img2, im.i2.data(), im.i2.size());
@@ -929,12 +941,12 @@ extern "C" int ev2h_pack_sa_images(const double* W2, const double* W3, int C1, i
 }
 
 extern "C" size_t ev2h_pack_gemm_image_bytes(int N, int K, int planes, int tile_rows) {
-    if (N <= 0 || K <= 0 || planes < 1 || planes > 3 || tile_rows <= 0) return 0;
-    return (size_t)(up(N, tile_rows) / tile_rows) * (up(K, 32) / 32) * tile_rows * (planes * 64 + 16);
+    if (N <= 0 || K <= 0 || planes < 1 || planes > 4 || tile_rows <= 0) return 0;
+    return (size_t)(up(N, tile_rows) / tile_rows) * (up(K, 32) / 32) * tile_rows * (npl(planes) * 64 + 16);
 }
 
 extern "C" int ev2h_pack_gemm_image(const double* W, int N, int K, int planes, int tile_rows, void* img, float* u) {
-    EV2H_CHECK_ARG(W && img && u && N > 0 && K > 0 && planes >= 1 && planes <= 3 && (tile_rows == 128 || tile_rows == 256));
+    EV2H_CHECK_ARG(W && img && u && N > 0 && K > 0 && planes >= 1 && planes <= 4 && (tile_rows == 128 || tile_rows == 256));
     EV2H_TRY
     const std::vector<uint8_t> im = gemm_image(W, N, K, planes, tile_rows, u);
     memcpy(img, im.data(), im.size());

@@ -7,6 +7,10 @@
 //                     tools/ubench/mfma_f16_denorm.hip)
 //   NS = 3  "bf16x3"  x = h + m + l, three bf16 planes by exact truncation (8 + 8 + 8 bits); products hl, lh, mm,
 //                     hm, mh, hh (dropped terms O(2^-24)); full fp32 range
+//   NS = 4  "f16"     [r6] ONE fp16 plane (h = rne(x), 11 mantissa bits: 8 x finer than bf16), 1 product, WITH the range
+//                     machinery of f16x2 (per-window power-of-two scaling from the range records, W / u planes) -- the
+//                     reduced-precision mode that survives a trained checkpoint (BASELINE.json config 3).  NS = 4 is a mode
+//                     CODE, not a plane count: plane_count(4) = 1, and the tile images have the bf16 mode's geometry.
 // Smallest terms are accumulated first.  The same splits are applied to the weights on the host (csrc/pack.hip).
 //
 // Range of f16x2 (fp16 has 5 exponent bits).  Weights: the host takes the planes of W / u, u a power of two (csrc/pack.hip:
@@ -26,14 +30,19 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// mode code -> number of 16-bit planes per operand / fp16 planes with range scaling (f16x2, f16)
+constexpr int plane_count(int ns) { return ns == 4 ? 1 : ns; }
+constexpr bool planes_f16(int ns) { return ns == 2 || ns == 4; }
+
 template <int NS> struct Planes;
 template <> struct Planes<1> { static constexpr int NPROD = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
 template <> struct Planes<2> { static constexpr int NPROD = 3; static constexpr int A[3] = {0, 1, 0}, B[3] = {1, 0, 0}; };
+template <> struct Planes<4> { static constexpr int NPROD = 1; static constexpr int A[1] = {0}, B[1] = {0}; };
 template <> struct Planes<3> { static constexpr int NPROD = 6; static constexpr int A[6] = {0, 2, 1, 0, 1, 0}, B[6] = {2, 0, 1, 1, 0, 0}; };
 
 template <int NS>
 __device__ __forceinline__ f32x16 mfma_planes(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (NS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if constexpr (planes_f16(NS)) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
@@ -49,9 +58,11 @@ __device__ __forceinline__ float trunc_hi16(float x) { return __uint_as_float(__
 // two fp32 values -> NS packed plane words (element 0 in the low half-word).  Residual subtracts stay scalar: packed
 // fp32 VALU ops are slower than two plain ones on gfx950 (the build also passes -fno-slp-vectorize).
 template <int NS>
-__device__ __forceinline__ void split_planes(float x0, float x1, unsigned (&o)[NS]) {
+__device__ __forceinline__ void split_planes(float x0, float x1, unsigned (&o)[plane_count(NS)]) {
     if constexpr (NS == 1) {
         o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+    } else if constexpr (NS == 4) {
+        o[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, f16x2));      // v_cvt_pk_f16_f32 (RNE)
     } else if constexpr (NS == 2) {
         // 4 VALU ops per pair: v_cvt_pk_f16_f32, two v_fma_mix_f32 that read the fp16 halves of the packed high plane
         // directly (residual x - float(h), exact), v_cvt_pk_f16_f32 -- bit-identical to the cvt / cvt-back / subtract form
@@ -76,6 +87,14 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned relu_pk_bf16(unsigned v) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), s16x2{0, 0}));
 }
+
+// packed fp16, NON-NEGATIVE values (after relu_pk_bf16): clamp +inf / NaN patterns (> 0x7bff as int16) to the largest finite fp16
+__device__ __forceinline__ unsigned sat_pk_f16(unsigned v) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2, v), s16x2{0x7bff, 0x7bff}));
+}
+// NOTE on inline asm in these kernels: an asm block must never be the FIRST consumer of an MFMA result -- the wait states between an
+// MFMA's register write and a VALU read are inserted by the compiler, which does not see into asm (a v_fma_mixlo_f16 asm on raw
+// accumulators read stale values, round 6).  split_planes<2>'s asm is fed by ordinary VALU results (scaled / clamped values) only.
 
 // ---- f16x2 activation range (see the header comment) --------------------------------------------------------------------
 // power of two s such that a * s lies in [2^14, 2^15) for the non-negative float with bit pattern `amax_bits`

@@ -5,6 +5,10 @@
 //           truncation split x = h + m + l) and the six products hh, hm, mh, mm, hl, lh are accumulated in
 //           fp32 -- dropped terms are O(2^-24), i.e. fp32-class accuracy at 6/16 of the fp32 MFMA cost;
 //   NS = 1  plain bf16 operands (round to nearest even), fp32 accumulate -- BASELINE.json config 3.
+//   NS = 4  "f16" [r6]: ONE fp16 plane per operand (11 mantissa bits, one MFMA per multiply-add like bf16) with f16x2's range
+//           machinery (range records, per-window powers of two, W / u planes); layer 1 is BF16's matrix-pipe form (L1M: ONE
+//           MFMA per chunk, inputs as two fp16 planes, weights as one) under wave-uniform powers of two.  NS = 4 is a mode code:
+//           plane_count(NS) = 1 planes are stored, planes_f16(NS) selects the fp16 MFMA and the range scaling (planes.hpp).
 // All biases, ReLUs and the max stay in fp32.  Layer 1 has three forms (see L1M / L1F / the VALU path in the kernel):
 //   * gathered layer-1 table row + exact fp32 relative-xyz fma chain (every mode when the features are a real table: enc.sa2);
 //   * BF16: one MFMA per 32-channel chunk (inputs as two bf16 planes), on top of the table row or -- raw feature rows -- instead of it;
@@ -18,6 +22,7 @@
 // (global_load_lds_dwordx4, no staging registers): two buffers and one barrier per tile step (one or two tiles) in the
 // streamed variant; the narrow MLPs keep all tiles resident in a persistent workgroup (see the kernel's comment).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include "planes.hpp"
@@ -57,6 +62,11 @@ struct SaBP {
     // F16X2 with raw feature rows: range record of the feature rows, the layer-1 bounds and the power-of-two plane factor of
     // [W1f | W1x] (ev2h_sa_desc)
     const unsigned* feat_amax; float w1f_norm, b1_max, u1f, u1x;
+    // F16 (NS = 4), layer 1 on the matrix pipe (L1M): launch-constant powers of two of the three k-slot groups of the A tile --
+    // A = [W1f / a1f | W1x / a1x | W1x / a1x | b1 / a1b | W1f / a1f], B = s1 [a1f f | a1x lo(d) | a1x hi(d) | a1b | a1f lo(f)] with the
+    // window's power of two s1 (chosen from the layer's rigorous bound, so that every B slot stays below 2^8 and every A entry below
+    // 2^9: see ev2h_sa_mlp_max_bf16)
+    float a1f, a1x, a1b;
     // streamed set abstraction, small grids: spg > 1 = the K / 32 strips of a group are spread over spg waves of one workgroup (a
     // workgroup then holds 8 / spg groups) and their partial maxima are combined through LDS -- a max is exact and order-free, so
     // the result is bit-identical; the weights are streamed once per strip SET instead of once per strip of the longest group.
@@ -93,27 +103,29 @@ constexpr int SAB_THREADS = SAB_WAVES * 64;
 
 template <int C1, int C2, int C3, int NS>
 struct SaBCfg {
+    static constexpr int NPL = plane_count(NS);                         // 16-bit planes per operand in the tile images
+    static constexpr bool F16 = planes_f16(NS);                         // fp16 planes: range records and power-of-two scaling
     static constexpr int T2 = (C2 + 31) / 32;
     static constexpr int REM = C2 % 32;
     static constexpr int M_LAST = REM == 0 ? 2 : (REM <= 16 ? 1 : 2);   // live 16-wide k-blocks of the last layer-2 tile
     static constexpr int C2P = 32 * (T2 - 1) + 16 * M_LAST;              // layer-3 contraction length (permuted order)
     static constexpr int T3 = C3 / 32;
     static constexpr int NC1 = C1 / 32;
-    static constexpr int RS2 = NS * 64 + 16;                             // bytes per row of a W2 chunk tile
-    static constexpr int RS3 = NS * C2P * 2 + 16;                        // bytes per row of a W3 tile
+    static constexpr int RS2 = NPL * 64 + 16;                             // bytes per row of a W2 chunk tile
+    static constexpr int RS3 = NPL * C2P * 2 + 16;                        // bytes per row of a W3 tile
     static constexpr int TB2 = T2 * 32 * RS2;
     static constexpr int TB3 = 32 * RS3;
     // streamed variant: a tile step moves CPT layer-2 chunk tiles or UPT layer-3 tiles at once (one DMA burst, one barrier);
     // two per step whenever the doubled buffers still fit in LDS (measured on 128-128-256 f16x2: -16 % with 2, -11 % with 4)
-    static constexpr int SB2W = (NS == 2) ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
+    static constexpr int SB2W = F16 ? SAB_WAVES * T2 * 32 * 4 : 0;   // F16X2: the b2 bias times each wave's window scale
     // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
     // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
     // BF16X3: three A tiles per channel row ([w0 | w0], [w1 | w1], [w2 | w0]: 96 B) + the b1 bias
-    static constexpr int W1B = (NS == 1) ? C1 * 32 : (NS == 2) ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 96 + C1 * 4;
+    static constexpr int W1B = (NS == 1 || NS == 4) ? C1 * 32 : F16 ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 96 + C1 * 4;
     // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, REC_SLOTS per-window running maxima
     // in the resident one -- see the kernel's epilogue
     static constexpr int REC_SLOTS = 64;
-    static constexpr int REC = (NS == 2) ? REC_SLOTS * 4 : 0;
+    static constexpr int REC = F16 ? REC_SLOTS * 4 : 0;
     static constexpr int SMALL_NOREC = W1B + T2 * 32 * 4 + 16 + SB2W;      // + b2, one int for the workgroup's strip count, scaled b2
     static constexpr int SMALL = SMALL_NOREC + REC;
     static constexpr int tile_bytes(int cpt, int upt) { return ((cpt * TB2 > upt * TB3 ? cpt * TB2 : upt * TB3) + 1023) / 1024 * 1024; }
@@ -164,7 +176,9 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // and with raw feature rows (<= 5 channels: enc.sa1, the regressors' sa1) no layer-1 table exists at all.  The D registers
     // of a lane are channels 8q + 4 half + e, so the layer-2 k slot (block m, half h, e) is channel 16m + 4h + (e & 3) + 8(e >> 2):
     // the BF16 W2 images are stored in that order (ev2h_tile_geometry out[9] = 1), for every kernel mode.
-    constexpr bool L1M = (NS == 1) && !ROWS;
+    // F16 (NS = 4) [r6]: the same form in fp16 -- the k-slot groups carry launch-constant powers of two (SaBP::a1f / a1x / a1b), the B
+    // operand the window's s1, so that D1 = s1 (W1f f + W1x d + b1) comes out of the MFMA ready for ReLU + conversion (2 VALU ops per pair).
+    constexpr bool L1M = (NS == 1 || NS == 4) && !ROWS;
     // F16X2, set abstraction with RAW FEATURE ROWS (ev2h_sa_desc.feat): layer 1 on the matrix pipe with a power-of-two scale PER
     // NEIGHBOUR.  The inputs of neighbour j -- features f0..f4 and relative xyz -- are two groups with their own weights (W1f / uf,
     // W1x / ux, planes built here) and their own input factors sigma_f = kappa_j uf, sigma_x = kappa_j ux, where
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // BF16X3 with raw feature rows [r5]: the same without any factor.  B1f = [x0(8) | x1(8)], B1g = [x0 | x2] (x = x0 + x1 + x2, the exact
     // three-plane split), A = [w2 | w0] (x B1g), [w1 | w1], [w0 | w0] (x B1f): three MFMAs = the six products of Planes<3>, small terms
     // first, on top of C = b1.
-    constexpr bool L1F = !ROWS && NS >= 2 && (!sab_split_forms<NS>() || MODE == 3);
+    constexpr bool L1F = !ROWS && (NS == 2 || NS == 3) && (!sab_split_forms<NS>() || MODE == 3);
     // L2PIPE / H2FUSE (round 4, late): conversion work of one wave placed between its MFMA groups (see the layer-2 loop and the first
     // layer-3 step).  Same-box step A/B (profiles/r4_ab_h2fuse_l2pipe.txt): BF16 +1.3 % with H2FUSE, +1.9 % with both; F16X2 +1.1 % with
     // H2FUSE, and L2PIPE costs it 0.5 % (its widest instantiation then spills 24 bytes) -- so F16X2 keeps the un-pipelined layer 2.
@@ -191,24 +205,30 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #ifdef EV2H_L2PIPE2
     constexpr bool L2PIPE = !ROWS && NS <= 2 && (C1 / 32) % 2 == 0;      // build experiment: F16X2 too
 #else
+#ifdef EV2H_F16_NO_L2PIPE
     constexpr bool L2PIPE = !ROWS && NS == 1 && (C1 / 32) % 2 == 0;
+#else
+    constexpr bool L2PIPE = !ROWS && (NS == 1 || NS == 4) && (C1 / 32) % 2 == 0;      // (F16 [r6]: bf16's layer-1 form, bf16's pipelining)
+#endif
 #endif
 #endif
 #ifdef EV2H_NO_H2FUSE
     constexpr bool H2FUSE = false;
 #else
-    constexpr bool H2FUSE = NS <= 2;          // (BF16X3: the widest instantiation would spill)
+    constexpr bool H2FUSE = NS != 3;          // (BF16X3: the widest instantiation would spill)
 #endif
     // F16X2 [r5]: with the two layer-1 forms in separate instantiations there are registers for the second fragment set (128-196-256:
     // 224 -> 232): dominant launch 1.622 -> 1.592 ms, step +0.65 % same-box (profiles/r5_ab_frag_pipe_f16x2.txt).  BF16X3 would spill
     // (28 bytes in the widest instantiation).  EV2H_BUILD_DEFS=-DEV2H_NO_FRAG_PIPE2: F16X2 without (A/B).
 #ifdef EV2H_NO_FRAG_PIPE2
-    constexpr bool FRAG_PIPE = (NS == 1);
+    constexpr bool FRAG_PIPE = (NS == 1 || NS == 4);
 #else
-    constexpr bool FRAG_PIPE = (NS <= 2);
+    constexpr bool FRAG_PIPE = (NS != 3);
 #endif
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
+    constexpr int NPL = Cfg::NPL;
+    constexpr bool F16 = Cfg::F16;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
     constexpr int WBYTES = RES ? Cfg::RES_W : 2 * Cfg::TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,30 +246,31 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     const bool hasfeat = sab_split_forms<NS>() ? (MODE == 3) : (p.feat != nullptr);
     const bool fmode = L1F && hasfeat;                         // (uniform)
     // F16X2 feature mode: s1 b1 of this wave's window; BF16X3 feature mode: b1 (one copy)
-    float* sb1w = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * 96);
+    float* sb1w = F16 ? reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * 96);
 
     if constexpr (L1M) {
         // A1 [C1][16 k] bf16 (one 32-byte row per channel), k slots as listed above
+        const float iaf = F16 ? 1.f / p.a1f : 1.f, iax = F16 ? 1.f / p.a1x : 1.f, iab = F16 ? 1.f / p.a1b : 1.f;      // (powers of two: exact)
         for (int i = tid; i < C1; i += WV * 64) {
             const float4 w = p.W1x[i];
             float k[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) k[j] = 0.f;
-            k[5] = k[8] = w.x; k[6] = k[9] = w.y; k[7] = k[10] = w.z;
+            k[5] = k[8] = w.x * iax; k[6] = k[9] = w.y * iax; k[7] = k[10] = w.z * iax;
             if (hasfeat) {
-                for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j];
+                for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iaf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) k[12 + j] = k[j];
-                k[11] = p.b1[i];
+                k[11] = p.b1[i] * iab;
             }
             unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 8;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { unsigned o[1]; split_planes<1>(k[2 * j], k[2 * j + 1], o); d[j] = o[0]; }
+            for (int j = 0; j < 8; ++j) { unsigned o[1]; split_planes<NS>(k[2 * j], k[2 * j + 1], o); d[j] = o[0]; }
         }
     } else if constexpr (!ROWS) {
         if (fmode) {
             // A tiles of layer 1: row i = [wh(v0..v7) | wh(v0..v7)] then [wl(v0..v7) | 0], v = (f0..f4, dx, dy, dz), planes of W1f / uf, W1x / ux
-            const float iu = (NS == 2) ? 1.f / p.u1f : 1.f, iux = (NS == 2) ? 1.f / p.u1x : 1.f;      // (powers of two: exact; BF16X3: no plane factor)
+            const float iu = F16 ? 1.f / p.u1f : 1.f, iux = F16 ? 1.f / p.u1x : 1.f;      // (powers of two: exact; BF16X3: no plane factor)
             for (int i = tid; i < C1; i += WV * 64) {
                 const float4 w = p.W1x[i];
                 float k[8];
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 for (int j = 0; j < 8; ++j) k[j] = 0.f;
                 for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iu;
                 k[5] = w.x * iux; k[6] = w.y * iux; k[7] = w.z * iux;
-                if constexpr (NS == 2) {
+                if constexpr (F16) {          // (F16 too: layer 1 keeps the two-plane form)
                     unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -287,14 +308,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     for (int i = tid; i < T2 * 32; i += WV * 64) sb2[i] = p.b2[i] / p.u2;     // accumulators hold (W2 h1 + b2) / u2 (exact: power of two)
     // F16X2: the accumulators hold (s1 / u2)(W2 h1 + b2) with the window's power of two s1; each wave keeps b2 s1 / u2 of its
     // window here, so that an accumulator tile is initialised by four LDS reads and no arithmetic
-    float* sbw = (NS == 2) ? reinterpret_cast<float*>(smem + WBYTES + Cfg::W1B + T2 * 32 * 4 + 16) + wave * (T2 * 32) : sb2;
+    float* sbw = F16 ? reinterpret_cast<float*>(smem + WBYTES + Cfg::W1B + T2 * 32 * 4 + 16) + wave * (T2 * 32) : sb2;
 
     // LDS-DMA of one tile image: each wave instruction moves 1 KiB (64 lanes x 16 B), lane-linear on both sides
     auto dma_tile = [&](const char* src, char* dst, int bytes) {
         for (int off = wave * 1024; off < bytes; off += WV * 1024) {
-#ifdef EV2H_SAB_DMA_EXPERIMENT      // timing experiment only (WRONG results): move 1 / EV2H_SAB_DMA_EXPERIMENT of the weight bytes
-            if ((off / (WV * 1024)) % EV2H_SAB_DMA_EXPERIMENT) continue;
-#endif
             if (off + lane * 16 < bytes)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     auto dma_w3 = [&](int step, char* dst) { dma_tile(p.W3s + (size_t)step * UPT * Cfg::TB3, dst, UPT * Cfg::TB3); };
 
     int buf = 0;
-    if constexpr (RES && NS == 2) {
+    if constexpr (RES && F16) {
         if (tid < Cfg::REC_SLOTS) reinterpret_cast<unsigned*>(smem + WBYTES + Cfg::SMALL_NOREC)[tid] = 0u;      // per-window running maxima of the record combine
     }
     if constexpr (RES) {
@@ -342,15 +360,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
     float s1 = 1.f, c2 = p.u2, c3 = p.u3;
-    if constexpr (NS == 2) {
-        if (fmode && p.feat_amax) {
+    float b1s_f = 1.f, b1s_x = 1.f, b1s_b = 1.f;               // F16 L1M: the B operand's factors s1 a1f, s1 a1x, s1 a1b (wave-uniform)
+    const bool fform = fmode || (L1M && hasfeat);               // layer 1 reads raw feature rows (no table, no producer that chose s1)
+    if constexpr (F16) {
+        if (fform && p.feat_amax) {
             // no table and no producer that chose s1: the same bound, evaluated here from the record of the feature rows
             const float bnd = __fmaf_rn(p.w1f_norm, __uint_as_float(p.feat_amax[b]), p.b1_max) + p.w1x_norm * p.dmax;
             s1 = f16x2_scale(__float_as_uint(bnd));
             const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bnd, p.b2_max)));
             c2 = p.u2 * s2 * pow2_inverse(s1);
             c3 = p.u3 * pow2_inverse(s2);
-        } else if (!fmode && p.p1_amax) {
+        } else if (!fform && p.p1_amax) {
             float a1 = __uint_as_float(p.p1_amax[b]);
             if constexpr (DIRECT) { s1 = f16x2_scale(p.p1_amax[b]); a1 *= s1; }       // unscaled input rows: scaled as they are read
             else s1 = p.p1_scale[b];
@@ -368,6 +388,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         if constexpr (L1F) {
             if (fmode) for (int i = lane; i < C1; i += 64) sb1w[i] = p.b1[i] * s1;
         }
+        if constexpr (L1M) { b1s_f = s1 * p.a1f; b1s_x = s1 * p.a1x; b1s_b = s1 * p.a1b; }      // (SGPRs: s1 is, the a1 are kernel arguments)
     }
     // Slots >= cnt of a group repeat slot 0 (ball-query padding, pointnet2_utils.py:104-106): 32-slot strips made only of
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
@@ -397,7 +418,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #ifdef EV2H_NO_XPF
     constexpr bool XPF = false;
 #else
-    constexpr bool XPF = !ROWS && NS <= 2;
+    constexpr bool XPF = !ROWS && NS != 3;
 #endif
     f32x4 raw[4];                 // a lane's 16 gathered layer-1 values of the current chunk (XPF: survives into the next strip)
     int idx_cur = 0, idx_nxt = 0;
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    raw[j4][e] = DIRECT ? ((NS == 2) ? trw[0][j4][e] * s1 : trw[0][j4][e])
+                    raw[j4][e] = DIRECT ? (F16 ? trw[0][j4][e] * s1 : trw[0][j4][e])
                                         : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
         if constexpr (DIRECT) {
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             const float4 q = XPF ? q_cur : p.pts4[(size_t)b * p.Npts + idx];
             if constexpr (XPF) idx_nxt = (strip + 1 < my_strips) ? gi[(strip + 1) * 32 + l31] : idx_cur;
             dx = __fsub_rn(q.x, ctr.x); dy = __fsub_rn(q.y, ctr.y); dz = __fsub_rn(q.z, ctr.z);
-            if constexpr (NS == 2) { if (!fmode) { dx *= s1; dy *= s1; dz *= s1; } }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
+            if constexpr (F16 && !L1M) { if (!fmode) { dx *= s1; dy *= s1; dz *= s1; } }      // exact; with P1' = s1 P1 this makes layer 1 produce s1 H1
             if (fmode) {
                 if constexpr (L1F && NS == 3) {
                     // (no XPF in this mode: the feature row is requested here)  B1f = [x0 | x1], B1g = [x0 | x2] of v = (f0..f4, dx, dy, dz)
@@ -499,7 +520,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         b1g[w] = half ? o[2] : o[0];
                     }
                 }
-                if constexpr (L1F && NS == 2) {
+                if constexpr (L1F && F16) {
                     // B1 = [xh(v0..v7) | xl(v0..v7)], v = (f0..f4, dx, dy, dz) of this lane's neighbour times its own power of two s_j
                     float v[8] = {f0_cur.x, f0_cur.y, f0_cur.z, f0_cur.w, f1_cur.x, dx, dy, dz};
                     const float af = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fabsf(v[4]));
@@ -525,6 +546,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 for (int j = 0; j < 8; ++j) f[j] = 0.f;
                 if (hasfeat) {
                     f[0] = f0_cur.x; f[1] = f0_cur.y; f[2] = f0_cur.z; f[3] = f0_cur.w; f[4] = f1_cur.x;
+                    if constexpr (F16) {
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) f[j] *= b1s_f;          // exact (power of two); < 2^8 by the choice of s1 and a1f
+                    }
                 } else {
                     prow = reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.Npts + idx) * p.ldp);
                     if (strip == 0) {          // (later strips: requested during the previous strip's layer 3)
@@ -532,13 +557,19 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         for (int j4 = 0; j4 < 4; ++j4) raw[j4] = *reinterpret_cast<const f32x4*>(prow + qi(j4));
                     }
                 }
-                auto lo_of = [](float x) { return x - __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, 0.f}, bf16x2)) << 16); };
-                const float va[8] = {f[0], f[1], f[2], f[3], f[4], lo_of(dx), lo_of(dy), lo_of(dz)};
-                const float vb[8] = {dx, dy, dz, 1.f, lo_of(f[0]), lo_of(f[1]), lo_of(f[2]), lo_of(f[3])};
+                // x minus its high 16-bit plane (bf16 / fp16, round to nearest even): exact
+                auto lo_of = [](float x) {
+                    if constexpr (F16) return x - (float)(_Float16)x;
+                    else return x - __uint_as_float(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, 0.f}, bf16x2)) << 16);
+                };
+                const float ex = F16 ? dx * b1s_x : dx, ey = F16 ? dy * b1s_x : dy, ez = F16 ? dz * b1s_x : dz;
+                const float va[8] = {f[0], f[1], f[2], f[3], f[4], lo_of(ex), lo_of(ey), lo_of(ez)};
+                // (the constant slot that carries b1: unused in table mode -- its A entry is 0 -- and there s1 alone may exceed fp16: 0 x inf)
+                const float vb[8] = {ex, ey, ez, F16 ? (hasfeat ? b1s_b : 0.f) : 1.f, lo_of(f[0]), lo_of(f[1]), lo_of(f[2]), lo_of(f[3])};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     unsigned o[1];
-                    split_planes<1>(half ? vb[2 * w] : va[2 * w], half ? vb[2 * w + 1] : va[2 * w + 1], o);
+                    split_planes<NS>(half ? vb[2 * w] : va[2 * w], half ? vb[2 * w + 1] : va[2 * w + 1], o);
                     b1f[w] = o[0];
                 }
             } else {
@@ -582,7 +613,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 for (int r = 0; r < 16; ++r) acc[r] = raw[r >> 2][r & 3];
             }
             const u32x4 a1 = *reinterpret_cast<const u32x4*>(smem + WBYTES + (32 * c + l31) * 32 + half * 16);
-            return mfma_planes<1>(a1, b1f, acc);
+            return mfma_planes<NS>(a1, b1f, acc);
             }
         };
         f32x16 d1;
@@ -613,14 +644,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         STAMP(1);
         // layer-1 finish in fp32, then split, of SLICE j4 of chunk c: the lane's channels 32c + 8 j4 + 4 half + [0, 4) = two of its 16
         // k-slots of the chunk (a chunk's 16 slots feed 2 MFMAs per tile: bp[k-block][plane])
-        auto finish_slice = [&](int c, int j4, u32x4 (&bp)[2][NS]) {
+        auto finish_slice = [&](int c, int j4, u32x4 (&bp)[2][NPL]) {
             if constexpr (L1M) {
-                // ReLU on the packed bf16 pairs: one v_pk_max_i16 per pair (negative floats are negative int16 patterns)
+                // ReLU on the packed bf16 / fp16 pairs: one v_pk_max_i16 per pair (negative floats are negative int16 patterns in both
+                // formats).  F16: D1 is s1 H1 already (the factors rode on the operands); + one v_pk_min_i16 that clamps an overflowed
+                // conversion (+inf = 0x7c00) to the largest fp16 -- what relu_sat_f16 does for the two-plane mode
 #pragma unroll
                 for (int w = 2 * j4; w < 2 * j4 + 2; ++w) {
                     unsigned o[1];
-                    split_planes<1>(d1[2 * w], d1[2 * w + 1], o);
-                    bp[w >> 2][0][w & 3] = relu_pk_bf16(o[0]);
+                    split_planes<NS>(d1[2 * w], d1[2 * w + 1], o);
+                    bp[w >> 2][0][w & 3] = F16 ? sat_pk_f16(relu_pk_bf16(o[0])) : relu_pk_bf16(o[0]);
                 }
             } else if (fmode) {
                 if constexpr (L1F && NS == 3) {
@@ -635,15 +668,15 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
                     }
                 }
-                if constexpr (L1F && NS == 2) {
+                if constexpr (L1F && F16) {
                     // s1 H1 = relu(D1 (u1 s1 / s_j) + s1 b1): D register 4q + e of a lane is channel 32c + 8q + 4 half + e
                     const int q = j4;
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb1w + 32 * c + 8 * q + 4 * half);
-                    unsigned lo[2], hi[2];
-                    split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q], cj, bv[0])), relu_sat_f16(__fmaf_rn(d1[4 * q + 1], cj, bv[1])), lo);
-                    split_planes<2>(relu_sat_f16(__fmaf_rn(d1[4 * q + 2], cj, bv[2])), relu_sat_f16(__fmaf_rn(d1[4 * q + 3], cj, bv[3])), hi);
+                    unsigned lo[NPL], hi[NPL];
+                    split_planes<NS>(relu_sat_f16(__fmaf_rn(d1[4 * q], cj, bv[0])), relu_sat_f16(__fmaf_rn(d1[4 * q + 1], cj, bv[1])), lo);
+                    split_planes<NS>(relu_sat_f16(__fmaf_rn(d1[4 * q + 2], cj, bv[2])), relu_sat_f16(__fmaf_rn(d1[4 * q + 3], cj, bv[3])), hi);
 #pragma unroll
-                    for (int s_ = 0; s_ < 2; ++s_) {
+                    for (int s_ = 0; s_ < NPL; ++s_) {
                         bp[q >> 1][s_][(q & 1) * 2 + 0] = lo[s_];
                         bp[q >> 1][s_][(q & 1) * 2 + 1] = hi[s_];
                     }
@@ -655,7 +688,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     v[e] = ROWS ? raw[j4][e] : __fmaf_rn(wz[e], dz, __fmaf_rn(wy[e], dy, __fmaf_rn(wx[e], dx, raw[j4][e])));
-                unsigned lo[NS], hi[NS];
+                unsigned lo[NPL], hi[NPL];
                 if constexpr (DIRECT) {                  // the rows are the layer's input as it is (|v| < 2^15 by the scale)
                     split_planes<NS>(v[0], v[1], lo);
                     split_planes<NS>(v[2], v[3], hi);
@@ -663,7 +696,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     split_planes<NS>(v[0], v[1], lo);
                     split_planes<NS>(v[2], v[3], hi);
                     lo[0] = relu_pk_bf16(lo[0]); hi[0] = relu_pk_bf16(hi[0]);
-                } else if constexpr (NS == 2) {
+                } else if constexpr (F16) {
                     split_planes<NS>(relu_sat_f16(v[0]), relu_sat_f16(v[1]), lo);
                     split_planes<NS>(relu_sat_f16(v[2]), relu_sat_f16(v[3]), hi);
                 } else {
@@ -671,7 +704,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                     split_planes<NS>(relu_bits(v[2]), relu_bits(v[3]), hi);
                 }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
+                for (int s = 0; s < NPL; ++s) {
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 0] = lo[s];
                     bp[j4 >> 1][s][(j4 & 1) * 2 + 1] = hi[s];
                 }
@@ -685,17 +718,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         // group -- the full LDS latency in front of every MFMA pair, which with ONE product per operand pair is most of a tile
         // step (phase timeline, profiles/r4_sa_timeline.txt: 1.0-1.7 us per 14-MFMA chunk whose MFMAs take 0.22 us).
         // between(pr) runs after the MFMAs of pair pr were issued (L2PIPE: slices of the next chunk's layer-1 finish).
-        auto mfma_groups = [&](const char* cur, u32x4 (&bp)[2][NS], auto&& between) {
+        auto mfma_groups = [&](const char* cur, u32x4 (&bp)[2][NPL], auto&& between) {
             const char* pa = cur + l31 * RS2 + (16 * half) * 2;
-            auto ld2 = [&](int pr, u32x4 (&x0)[NS], u32x4 (&x1)[NS]) {
+            auto ld2 = [&](int pr, u32x4 (&x0)[NPL], u32x4 (&x1)[NPL]) {
                 const int m0 = (2 * pr) / T2, t0 = (2 * pr) % T2, m1 = (2 * pr + 1) / T2, t1 = (2 * pr + 1) % T2;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
+                for (int s = 0; s < NPL; ++s) {
                     x0[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t0 * RS2 + s * 64 + m0 * 16);
                     x1[s] = *reinterpret_cast<const u32x4*>(pa + 32 * t1 * RS2 + s * 64 + m1 * 16);
                 }
             };
-            u32x4 fa[2][2][NS];
+            u32x4 fa[2][2][NPL];
             if constexpr (FRAG_PIPE) ld2(0, fa[0][0], fa[0][1]);
 #pragma unroll
             for (int pr = 0; pr < T2; ++pr) {
@@ -706,8 +739,8 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                 } else {
                     ld2(pr, fa[pr & 1][0], fa[pr & 1][1]);
                 }
-                u32x4 (&a0)[NS] = fa[pr & 1][0];
-                u32x4 (&a1)[NS] = fa[pr & 1][1];
+                u32x4 (&a0)[NPL] = fa[pr & 1][0];
+                u32x4 (&a1)[NPL] = fa[pr & 1][1];
 #pragma unroll
                 for (int j = 0; j < PL::NPROD; ++j) {
                     // PACK4: the last tile's high-plane image carries its low plane in rows 8..11 (see SaBCfg)
@@ -735,7 +768,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             }
             STAMP(5 + 4 * c);
         };
-        u32x4 bpA[2][NS];
+        u32x4 bpA[2][NPL];
         if constexpr (!L2PIPE) {
 #pragma unroll 1
             for (int c = 0; c < NC1; ++c) {
@@ -775,14 +808,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             // L2PIPE: the layer-1 finish + split of chunk c + 1 is cut into its four slices and placed BETWEEN the MFMA pairs of chunk c
             // (two operand buffers), so that one wave's conversion runs under its SIMD partner's MFMAs instead of both waves
             // converting behind the same barrier while the matrix pipe idles (phase timeline: 13 % of an f16x2 strip).
-            u32x4 bpB[2][NS];
+            u32x4 bpB[2][NPL];
             const bool vtab = !L1M && !fmode;            // layer 1 on the VALU from gathered table rows
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4) {
                 finish_slice(0, j4, bpA);
                 if (vtab) raw[j4] = *reinterpret_cast<const f32x4*>(prow + 8 + qi(j4));
             }
-            auto l2_step = [&](int c, u32x4 (&bc)[2][NS], u32x4 (&bn)[2][NS]) {
+            auto l2_step = [&](int c, u32x4 (&bc)[2][NPL], u32x4 (&bn)[2][NPL]) {
                 STAMP(2 + 4 * c);
                 char* cur = RES ? smem + c * Cfg::TB2 : (buf ? wt1 : wt0) + (c % CPT) * Cfg::TB2;
                 l2_dma(c);
@@ -841,17 +874,17 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int r = 0; r < 4; ++r) { h2[T2 - 1][r] += h2[T2 - 1][r + 4]; h2[T2 - 1][r + 4] = 0.f; }
         }
         // ReLU in fp32 (the bias is already in), then split in place: h2p[s][t][k] packs D2 rows (2k, 2k+1) of tile t
-        u32x4 h2p[NS][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
+        u32x4 h2p[NPL][T2][2];        // [plane][tile][k-block m]: directly in MFMA A-operand form
         // one k-block (8 channels per lane) of tile t; PACK4: the last tile's block 0 is re-packed once both planes exist
         auto split_half = [&](int t, int m) {
 #pragma unroll
             for (int k = 4 * m; k < 4 * m + 4; ++k) {
-                unsigned o[NS];
-                if constexpr (NS == 2) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
+                unsigned o[NPL];
+                if constexpr (F16) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
                 else if constexpr (NS == 1) { split_planes<NS>(h2[t][2 * k], h2[t][2 * k + 1], o); o[0] = relu_pk_bf16(o[0]); }     // (u2 = 1: no factor)
                 else split_planes<NS>(relu_bits(h2[t][2 * k] * c2), relu_bits(h2[t][2 * k + 1] * c2), o);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
+                for (int s = 0; s < NPL; ++s) h2p[s][t][k >> 2][k & 3] = o[s];
             }
             if constexpr (Cfg::PACK4) {
                 if (t == T2 - 1 && m == 0) {
@@ -908,14 +941,14 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
             const char* pb = cur + l31 * RS3 + (8 * half) * 2;
             constexpr int NG3 = 2 * (T2 - 1) + Cfg::M_LAST;       // live (tile, k-block) groups of the contraction
-            auto ld3 = [&](int g, u32x4 (&x)[NS], u32x4 (&x1)[TPS == 2 ? NS : 1]) {
+            auto ld3 = [&](int g, u32x4 (&x)[NPL], u32x4 (&x1)[TPS == 2 ? NPL : 1]) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
+                for (int s = 0; s < NPL; ++s) {
                     x[s] = *reinterpret_cast<const u32x4*>(pb + s * (C2P * 2) + (16 * g) * 2);
                     if constexpr (TPS == 2) x1[s] = *reinterpret_cast<const u32x4*>(pb + Cfg::TB3 + s * (C2P * 2) + (16 * g) * 2);
                 }
             };
-            u32x4 fw[2][NS], fw1[2][TPS == 2 ? NS : 1];
+            u32x4 fw[2][NPL], fw1[2][TPS == 2 ? NPL : 1];
             if constexpr (FRAG_PIPE) ld3(0, fw[0], fw1[0]);
 #pragma unroll
             for (int t = 0; t < T2; ++t) {
@@ -929,11 +962,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                         } else {
                             ld3(g, fw[g & 1], fw1[g & 1]);
                         }
-                        u32x4 a[NS];
-                        u32x4 (&w)[NS] = fw[g & 1];
-                        u32x4 (&w1)[TPS == 2 ? NS : 1] = fw1[g & 1];
+                        u32x4 a[NPL];
+                        u32x4 (&w)[NPL] = fw[g & 1];
+                        u32x4 (&w1)[TPS == 2 ? NPL : 1] = fw1[g & 1];
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) a[s] = h2p[s][t][m];
+                        for (int s = 0; s < NPL; ++s) a[s] = h2p[s][t][m];
                         // operand roles swapped w.r.t. layer 2: activations are A, weights are B
 #pragma unroll
                         for (int j = 0; j < PL::NPROD; ++j) {
@@ -1040,7 +1073,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         if (p.xyz_out && valid && sw == 0 && lane < 8)
             p.xyz_out[(size_t)g * p.xyz_ld + lane] = lane == 0 ? ctr.x : lane == 1 ? ctr.y : lane == 2 ? ctr.z : 0.f;
     }
-    if constexpr (NS == 2) {
+    if constexpr (F16) {
         // Range record of the output (ev2hands_hip.h "Range records"): amax[b] = max over the window's groups.  One device-scope
         // atomicMax per GROUP put 512 read-modify-writes on one address per window and launch; across the 8 XCDs these are
         // executed one after the other at the memory side, and a launch of a few windows (16 windows of 8192 points = one rank's
@@ -1196,9 +1229,9 @@ int geometry_ns(int c1, int c2, int c3, int out[10]) {
 }  // namespace
 
 extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10]) {
-    EV2H_CHECK_ARG(out && planes >= 1 && planes <= 3);
+    EV2H_CHECK_ARG(out && planes >= 1 && planes <= 4);        // (4 = the mode code of "f16": one fp16 plane, planes.hpp)
     for (int i = 0; i < 10; ++i) out[i] = 0;
-    const int rc = planes == 1 ? geometry_ns<1>(C1, C2, C3, out) : planes == 2 ? geometry_ns<2>(C1, C2, C3, out) : geometry_ns<3>(C1, C2, C3, out);
+    const int rc = planes == 1 ? geometry_ns<1>(C1, C2, C3, out) : planes == 2 ? geometry_ns<2>(C1, C2, C3, out) : planes == 3 ? geometry_ns<3>(C1, C2, C3, out) : geometry_ns<4>(C1, C2, C3, out);
     if (rc) { ev2h_set_error("ev2h_tile_geometry: unsupported chain %d-%d-%d", C1, C2, C3); return rc; }
     return ev2h_gemm_tile_geometry(planes, out + 6);
 }
@@ -1224,7 +1257,7 @@ int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_
     p.out_cm_stride = d->out_cm_stride ? d->out_cm_stride : (size_t)ncols * d->N;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * p.S, SAB_WAVES);
-    if (d->precision == EV2H_PREC_F16X2) {
+    if (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) {
         p.out_amax = d->out_amax;
         if (d->t_amax) {
             EV2H_CHECK_ARG(d->w2_norm >= 0.f && d->b2_max >= 0.f);
@@ -1237,6 +1270,7 @@ int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_fp<3>(p, d, st);
     if (d->precision == EV2H_PREC_F16X2) return dispatch_fp<2>(p, d, st);
     if (d->precision == EV2H_PREC_BF16) return dispatch_fp<1>(p, d, st);
+    if (d->precision == EV2H_PREC_F16) return dispatch_fp<4>(p, d, st);
     ev2h_set_error("ev2h_fp_mlp: precision %d is not a 16-bit plane mode (F32: ev2h_three_nn_interp + ev2h_gemm)", d->precision);
     return EV2H_ERR_ARG;
 }
@@ -1258,7 +1292,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
         p.feat = d->feat; p.ldf = d->ldf; p.W1f = d->W1f; p.ldw1f = d->ldw1f; p.b1 = d->b1; p.nfeat = d->nfeat;
         p.u1f = d->w1f_unscale > 0.f ? d->w1f_unscale : 1.f;
         p.u1x = d->w1x_unscale > 0.f ? d->w1x_unscale : 1.f;
-        if (d->precision == EV2H_PREC_F16X2 && d->feat_amax) {
+        if ((d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) && d->feat_amax) {
             EV2H_CHECK_ARG(d->dmax > 0.f && d->w1f_norm >= 0.f && d->b1_max >= 0.f && d->w1x_norm >= 0.f && d->w2_norm >= 0.f && d->b2_max >= 0.f);
             p.feat_amax = d->feat_amax; p.w1f_norm = d->w1f_norm; p.b1_max = d->b1_max;
             p.w1x_norm = d->w1x_norm; p.dmax = d->dmax; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
@@ -1267,7 +1301,7 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
         EV2H_CHECK_ARG(d->P1 != nullptr);
     }
     if (d->precision == EV2H_PREC_BF16) EV2H_CHECK_ARG(p.u2 == 1.f);      // (the BF16 layer-2 epilogue applies no factor)
-    if (d->precision == EV2H_PREC_F16X2) {
+    if (d->precision == EV2H_PREC_F16X2 || d->precision == EV2H_PREC_F16) {
         p.out_amax = d->out_amax;
         if (d->p1_scale) {
             EV2H_CHECK_ARG(d->p1_amax && d->dmax > 0.f && d->w1x_norm >= 0.f && d->w2_norm >= 0.f && d->b2_max >= 0.f);
@@ -1275,10 +1309,20 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
             p.w1x_norm = d->w1x_norm; p.dmax = d->dmax; p.w2_norm = d->w2_norm; p.b2_max = d->b2_max;
         }
     }
+    p.a1f = p.a1x = p.a1b = 1.f;
+    if (d->precision == EV2H_PREC_F16 && (p.feat_amax || p.p1_scale)) {
+        // F16 layer 1 (L1M): A = W / a with a = 2^(floor(log2 |W|_1) - 8) per k-slot group, B = s1 a x.  s1 keeps s1 (|W1f|_1 max|f| +
+        // max|b1| + |W1x|_1 dmax) below 2^15 (the kernel's bound / the table's storage scale), so each group's B slots stay below
+        // 2^15 a / |W|_1 <= 2^7 and each A entry below |W|_1 / a < 2^9: nothing overflows, whatever the checkpoint and the input
+        auto pow2_below = [](float norm) { int e = 0; if (!(norm > 0.f) || !std::isfinite(norm)) return 1.f; (void)std::frexp(norm, &e); return std::ldexp(1.f, e - 1 - 8); };
+        p.a1x = pow2_below(d->w1x_norm);
+        if (d->feat) { p.a1f = pow2_below(d->w1f_norm); p.a1b = pow2_below(d->b1_max); }
+    }
     hipStream_t st = (hipStream_t)stream;
     if (d->precision == EV2H_PREC_BF16X3) return dispatch_sab<3>(p, d->C1, d->C2, d->C3, st);
     if (d->precision == EV2H_PREC_F16X2) return dispatch_sab<2>(p, d->C1, d->C2, d->C3, st);
     if (d->precision == EV2H_PREC_BF16) return dispatch_sab<1>(p, d->C1, d->C2, d->C3, st);
+    if (d->precision == EV2H_PREC_F16) return dispatch_sab<4>(p, d->C1, d->C2, d->C3, st);
     ev2h_set_error("ev2h_sa_mlp_max: unknown precision %d", d->precision);
     return EV2H_ERR_ARG;
 }

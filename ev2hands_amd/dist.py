@@ -92,6 +92,34 @@ def all_gather_outputs(out: dict, N: int, group=None, global_batch: int | None =
     return unpack_outputs(rows, N, n_pose)
 
 
+def _group_moves_device_memory(group) -> bool:
+    """Can this process group run a collective on CUDA tensors?  Asked of the group itself, not of its name: a group made by
+    init_process_group() without a backend ("cpu:gloo,cuda:nccl") reports another string than "nccl" and still moves device memory."""
+    try:
+        be = group._get_backend(torch.device("cuda")) if group is not None else dist.distributed_c10d._get_default_group()._get_backend(torch.device("cuda"))
+        name = type(be).__name__.lower()
+        return "nccl" in name or "rccl" in name
+    except Exception:  # noqa: BLE001 -- no backend registered for cuda devices
+        pass
+    try:
+        return "nccl" in str(dist.get_backend_config(group)).lower()
+    except Exception:  # noqa: BLE001
+        return str(dist.get_backend(group)).lower() == "nccl"
+
+
+_warned_host_staged = False
+
+
+def _warn_host_staged(backend) -> None:
+    global _warned_host_staged
+    if not _warned_host_staged:
+        _warned_host_staged = True
+        import warnings
+        warnings.warn(f"ev2hands_amd.dist: the process group (backend {backend!r}) cannot move device memory -- the gather is staged through "
+                      "pinned host memory with a host synchronisation per step (the path of the CPU tests and of two ranks sharing one GPU). "
+                      "A multi-GPU run wants backend 'nccl' (RCCL).", RuntimeWarning, stacklevel=3)
+
+
 class GatherBuffer:
     """This rank's persistent all-gather buffer: float32 [world * big, packed_width(N)], big = the largest shard.
 
@@ -108,7 +136,9 @@ class GatherBuffer:
         # (gloo: the CPU tests, and tests/test_gpu_dist.py's two ranks that SHARE one GPU, which RCCL refuses) is served through a
         # pinned host mirror of the buffer: D2H of this rank's slice, the same in-place all_gather_into_tensor on the mirror, H2D
         # of the whole.  Only bytes move; the predictions are the forward's, bit for bit.
-        self.host_staged = torch.device(device).type == "cuda" and dist.get_backend(group) != "nccl"
+        self.host_staged = torch.device(device).type == "cuda" and not _group_moves_device_memory(group)
+        if self.host_staged:
+            _warn_host_staged(dist.get_backend(group))
         if global_batch < self.world:
             # a rank without a window would skip its forward (ev2h_forward needs B > 0) while the others wait in the collective:
             # refused here, on EVERY rank (the sizes are a pure function of global_batch and the world size)
@@ -185,12 +215,50 @@ class GatherPipeline:
                     self._out = unpack_outputs(torch.cat([b.full[r * b.big:r * b.big + b.sizes[r]] for r in range(b.world)], 0), b.N, b.n_pose)
             return self._out
 
-    def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2, n_pose: int = synth.MANO_CMPS):
+    def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2, n_pose: int = synth.MANO_CMPS, inflight: int = 0, net=None):
+        """inflight = K > 1 (with net = the TEHNetWrapper): `forward(xyz)` is then ONE call per step -- forward i runs on slot stream
+        i mod K with its own workspace (ev2hands_amd/inflight.py: a rank's share can be too small to fill its GPU; 16 windows of 8192
+        points: +20 % with two in flight), writes into gather buffer i mod depth and the asynchronous all-gather is issued from
+        the SLOT'S stream right behind it, so that the caller's stream never waits for a forward.  The reference's analogue is the one
+        `net(lnes)` call under nn.DataParallel (train.py:68,83).  depth is raised to K (two forwards in flight never share a buffer)."""
         if depth < 1:
             raise ValueError("depth >= 1")
+        self.inflight = None
+        if inflight and inflight > 1:
+            if net is None:
+                raise ValueError("GatherPipeline(inflight=K) needs net= (the TEHNetWrapper whose forwards it issues)")
+            from .inflight import InflightForward
+            self.inflight = InflightForward(net, inflight)
+            depth = max(depth, inflight)
+        self.net = net
         self.bufs = [GatherBuffer(N, global_batch, device, group, n_pose) for _ in range(depth)]
         self.pending = [None] * depth
         self.i = 0
+
+    def forward(self, xyz: torch.Tensor, fps_init=None, post=None) -> "GatherPipeline.Pending":
+        """One step: this rank's batch through the network into the next gather buffer, then the all-gather in flight.  Returns the
+        Pending of that gather (result() = the GLOBAL predictions).  fps_init: this rank's slice of the globally drawn FPS start
+        vectors (shard_fps_inits); post: optional callable(out) queued right behind the forward (before the gather)."""
+        if self.net is None:
+            raise ValueError("GatherPipeline.forward needs net= at construction")
+        if fps_init is not None:
+            self.net.net.fps_init = fps_init
+        if self.inflight is None:
+            with torch.no_grad():
+                out = self.net.net(xyz, self.net.hands, rows=self.rows())
+            if post is not None:
+                post(out)
+            return self.submit()
+        box = []
+
+        def after(out):
+            if post is not None:
+                post(out)
+            box.append(self.submit())                       # issued on the slot's stream: RCCL orders the collective behind the forward
+
+        # rows(): on the SLOT'S stream -- it waits for the gather that last read this buffer, the caller's stream waits for nothing
+        self.inflight.submit(xyz, pre=self.rows, post=after)
+        return box[0]
 
     def rows(self) -> torch.Tensor:
         p = self.pending[self.i]
@@ -206,6 +274,8 @@ class GatherPipeline:
         return p
 
     def drain(self) -> None:
+        if self.inflight is not None:
+            self.inflight.drain()                           # the caller's stream waits for every slot's forwards (and gathers' issue)
         for p in self.pending:
             if p is not None:
                 p.wait()

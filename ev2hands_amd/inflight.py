@@ -13,6 +13,8 @@ Numbers are unchanged by construction: the same ev2h_forward with the same argum
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from . import _lib
@@ -29,14 +31,18 @@ class InflightForward:
 
     A slot (stream + workspace) is reused every `depth` submissions; submit() makes the slot's stream wait for the caller's
     current stream first (the input is ready) and for the slot's previous forward by stream order.  `rows=` as in TEHNet.forward
-    (the multi-GPU gather buffer)."""
+    (the multi-GPU gather buffer; `dist.GatherPipeline(..., inflight=K)` composes the two).
+
+    One host thread at a time: every slot's forward forks onto the library's ONE side stream (per host thread and device) and joins
+    it with the library's events, which is correct for interleaved forwards only when their enqueue calls do not interleave --
+    submit() holds a lock for the duration of the enqueue."""
 
     class Ticket:
-        def __init__(self, out, event):
-            self.out, self.event = out, event
+        def __init__(self, out, event, device):
+            self.out, self.event, self.device = out, event, device
 
         def result(self) -> dict:
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(self.device)          # the stream of the OUTPUTS' device, whatever the current device is
             cur.wait_event(self.event)
             # the tensors were allocated on the slot's stream and are now used on the caller's: tell the caching allocator
             for v in self.out.values():
@@ -49,12 +55,17 @@ class InflightForward:
         if depth < 1:
             raise ValueError("depth >= 1")
         self.net, self.depth, self.i = net, depth, 0
-        self.streams, self.ws = None, [None] * depth
+        self.streams, self.ws, self.device = None, [None] * depth, None
+        self._lock = threading.Lock()
 
     def _slot(self, device, nbytes: int):
         if self.streams is None:
-            _lib.lib().ev2h_init()                      # the library's side stream first (it wants a hardware queue of its own)
+            with torch.cuda.device(device):             # the library's side stream first, ON THIS DEVICE (it wants a hardware queue of its own)
+                _lib.check(_lib.lib().ev2h_init(), "ev2h_init")
             self.streams = [torch.cuda.Stream(device) for _ in range(self.depth)]
+            self.device = torch.device(device)
+        elif torch.device(device) != self.device:
+            raise RuntimeError(f"InflightForward was started on {self.device}, got a batch on {device}")
         k = self.i % self.depth
         self.i += 1
         if self.ws[k] is None or self.ws[k].numel() < nbytes:
@@ -64,23 +75,28 @@ class InflightForward:
                 self.ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self.streams[k], self.ws[k]
 
-    def submit(self, xyz: torch.Tensor, rows=None, post=None) -> "InflightForward.Ticket":
+    def submit(self, xyz: torch.Tensor, rows=None, post=None, pre=None) -> "InflightForward.Ticket":
         """post: optional callable(out) run right behind the forward ON THE SLOT'S STREAM (e.g. the collision term of the same
-        batch) -- work queued on the caller's stream instead would make the next submit() wait for it."""
+        batch, or the all-gather of its predictions) -- work queued on the caller's stream instead would make the next submit() wait
+        for it.  pre: optional callable() run on the slot's stream BEFORE the forward and returning its `rows` (dist.GatherPipeline:
+        wait for the gather that last read the buffer, then hand its rows out)."""
         B, _, N = xyz.shape
-        stream, ws = self._slot(xyz.device, _lib.lib().ev2h_workspace_bytes(B, N))
-        stream.wait_stream(torch.cuda.current_stream(xyz.device))
-        with torch.cuda.stream(stream), torch.no_grad():
-            out = self.net.net(xyz, self.net.hands, rows=rows, ws=ws)
-            if post is not None:
-                post(out)
-            ev = torch.cuda.Event()
-            ev.record(stream)
-        xyz.record_stream(stream)
-        return InflightForward.Ticket(out, ev)
+        with self._lock:
+            stream, ws = self._slot(xyz.device, _lib.lib().ev2h_workspace_bytes(B, N))
+            stream.wait_stream(torch.cuda.current_stream(xyz.device))
+            with torch.cuda.stream(stream), torch.no_grad():
+                if pre is not None:
+                    rows = pre()
+                out = self.net.net(xyz, self.net.hands, rows=rows, ws=ws)
+                if post is not None:
+                    post(out)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            xyz.record_stream(stream)
+        return InflightForward.Ticket(out, ev, xyz.device)
 
     def drain(self) -> None:
         if self.streams:
-            cur = torch.cuda.current_stream()
+            cur = torch.cuda.current_stream(self.device)
             for s in self.streams:
                 cur.wait_stream(s)

@@ -106,7 +106,11 @@ class TEHNet(nn.Module):
         # OWN batch and keeps "f16x2" only if every output agrees with "bf16x3" to AUTO_TOLERANCE and the segmentation argmax is
         # identical; else "bf16x3".  A user who drops in a checkpoint therefore gets the check without asking for it; benchmarks
         # and tests name their mode (EV2H_PRECISION / precision=).
+        # "f16" [r6]: the reduced-precision mode (BASELINE config 3): ONE fp16 plane per operand under f16x2's range records -- bf16's
+        # cost, 8 x finer.  f16_families (EV2H_F16_FAMILIES): _lib.FAM_* mask of the kernel families that run reduced in that mode
+        # (0 / 15 = all; the others run f16x2).
         self.precision = os.getenv("EV2H_PRECISION", "auto")
+        self.f16_families = int(os.getenv("EV2H_F16_FAMILIES", "0")) & 15
         self._auto = None             # (pack key of the weights, chosen mode, report) of the last "auto" decision
         # exact power-of-two equalisation of the hidden channels when the checkpoint is packed (ev2h_pack_weights, csrc/pack.hip: equalize_channels): the
         # fp32 function is unchanged bit for bit, the 16-bit planes see well-conditioned operands whatever the BatchNorm scales are
@@ -115,6 +119,8 @@ class TEHNet(nn.Module):
         self.right_query_conv = _query_conv()
         self._packed = None
         self._packed_key = None
+        self._packed_spare = None     # (key, image) of the other candidate while "auto" decides
+        self._keep_spare = False
         self._key_tensors = None
         self._key_gen = 0
         self._faces_cache = {}
@@ -176,10 +182,21 @@ class TEHNet(nn.Module):
 
     def packed(self, device) -> PackedWeights:
         prec = self.effective_precision()
-        key = (str(device), prec, self.equalize, self._pack_key())
+        key = (str(device), prec, self.equalize, self.f16_families, self._pack_key())
         if self._packed is None or self._packed_key != key:
-            self._packed = None                   # (free the old device image first)
-            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, prec, equalize=self.equalize)
+            # one spare image: while "auto" decides (f16x2 vs bf16x3 on the first batch) both candidates stay packed, so that the
+            # forward after the decision does not pack the winner a second time; the loser is dropped by _auto_decide
+            spare = getattr(self, "_packed_spare", None)
+            if spare is not None and spare[0] == key:
+                self._packed_spare = (self._packed_key, self._packed) if self._keep_spare else None
+                self._packed, self._packed_key = spare[1], key
+                return self._packed
+            if self._keep_spare and self._packed is not None:
+                self._packed_spare = (self._packed_key, self._packed)
+            else:
+                self._packed_spare = None
+                self._packed = None               # (free the old device image first)
+            self._packed = PackedWeights(self.state_dict(), device, self.in_channels, prec, equalize=self.equalize, f16_families=self.f16_families)
             self._packed_key = key
         return self._packed
 
@@ -339,16 +356,42 @@ class TEHNet(nn.Module):
         return rep
 
     def _auto_decide(self, xyz, mano_hands, inits):
+        """The "auto" decision (once per set of weights): f16x2 against bf16x3 on THIS batch.  Costs two extra forwards and two packs
+        (both images stay packed until the decision is taken; the loser is dropped).
+        Under torch.distributed the decision is COLLECTIVE: every rank verifies on its own shard and the group takes the minimum
+        (one small all-reduce), so that all ranks run the same arithmetic -- a lone rank on bf16x3 would break sharded == unsharded
+        and stall every all-gather at 0.6 x the others' rate.  Every rank therefore has to reach its first forward
+        (and the first after a weight change); name a mode (precision= / EV2H_PRECISION) where ranks may diverge in that."""
         key = (str(xyz.device), self.equalize, self._pack_key())
         if self._auto is not None and self._auto[0] == key:
             return
         self._auto = None
         self.precision = "f16x2"
+        self._keep_spare = True
         try:
             rep = self.verify_precision(xyz, mano_hands, fps_init=inits)
         finally:
             self.precision = "auto"
-        self._auto = (key, "f16x2" if rep["ok"] else "bf16x3", rep)
+            self._keep_spare = False
+        ok = bool(rep["ok"])
+        rep["ok_this_rank"] = ok
+        try:
+            import torch.distributed as tdist
+            if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+                from .dist import _group_moves_device_memory
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=xyz.device if _group_moves_device_memory(None) else "cpu")
+                tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+                ok = bool(int(t.item()))
+                rep["ranks"] = tdist.get_world_size()
+        except ImportError:
+            pass
+        rep["ok"] = ok
+        self._auto = (key, "f16x2" if ok else "bf16x3", rep)
+        # drop the image that lost (the winner is `_packed` or the spare; packed() swaps it in without packing again)
+        want = (str(xyz.device), self._auto[1], self.equalize, self.f16_families, self._pack_key())
+        if self._packed_key != want and self._packed_spare is not None and self._packed_spare[0] == want:
+            self._packed, self._packed_key = self._packed_spare[1], want
+        self._packed_spare = None
 
     @property
     def auto_report(self):
@@ -405,10 +448,15 @@ class TEHNet(nn.Module):
         L = _lib.lib()
         cnt = C.c_size_t(0)
         ws = self._last_ws
-        p = L.ev2h_workspace_buffer(ws.data_ptr(), B, N, name.encode(), C.byref(cnt))
+        et = C.c_int(0)
+        p = L.ev2h_workspace_buffer_ex(ws.data_ptr(), B, N, name.encode(), C.byref(cnt), C.byref(et))
         if not p:
             raise KeyError(name)
         off = p - ws.data_ptr()
+        if et.value == 1:             # the last forward stored this buffer as bf16 (BF16 mode: l0): widened here, `cnt` counts VALUES
+            if dtype != torch.float32:
+                raise TypeError(f"workspace buffer {name!r} holds bf16 values in this mode: ask for float32")
+            return ws[off:off + cnt.value * 2].view(torch.bfloat16).float()
         return ws[off:off + cnt.value * 4].view(dtype).clone()
 
 

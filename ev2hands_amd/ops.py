@@ -142,8 +142,8 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     cnt [B,S] int32 (optional): distinct neighbours per group (query_ball_point's count); padding strips are skipped.
     p1_scale [B] float32 / p1_amax [B] range record / dmax / out_amax: the F16X2 range arguments of ev2h_sa_desc (P1 then
     holds p1_scale[b] * table)."""
-    if feat is not None and P1 is None and precision not in ("bf16", "f16x2", "bf16x3"):
-        raise ValueError(f"sa_mlp_max: feature rows without a layer-1 table need a plane precision ('bf16', 'f16x2', 'bf16x3'), not {precision!r}")
+    if feat is not None and P1 is None and precision not in ("bf16", "f16x2", "bf16x3", "f16"):
+        raise ValueError(f"sa_mlp_max: feature rows without a layer-1 table need a plane precision ('bf16', 'f16x2', 'bf16x3', 'f16'), not {precision!r}")
     if feat is not None:
         # "bf16" / "f16x2" / "bf16x3": layer 1 from the raw feature rows feat [B,Npts,8] (first W1f.shape[1] <= 5 columns used) with W1f [C1,nfeat],
         # b1 [C1] -- no table (P1 may be None); feat_amax [B] range record of the rows + dmax: F16X2 range handling
@@ -160,7 +160,7 @@ def sa_mlp_max(P1, pts4, ctr4, gidx, W1x, W2, b2, W3, b3, C2: int, precision: st
     if feat is not None:
         W1fc, b1c = W1f.contiguous(), b1.contiguous()
         d.feat, d.ldf, d.W1f, d.ldw1f, d.b1, d.nfeat = feat.data_ptr(), feat.shape[2], W1fc.data_ptr(), W1fc.shape[1], b1c.data_ptr(), W1fc.shape[1]
-        if precision == "f16x2":
+        if precision in ("f16x2", "f16"):
             from .pack import NS_OF, plane_unscale
             d.w1f_unscale = plane_unscale(W1fc.detach().cpu().double().numpy(), NS_OF[precision])
             d.w1x_unscale = plane_unscale(W1x[:, :3].detach().cpu().double().numpy(), NS_OF[precision])

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 
-NS_OF = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}     # operand planes per precision (csrc/planes.hpp)
+NS_OF = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3, "f16": 4}     # plane-mode code per precision (csrc/planes.hpp; 4 = "f16": ONE fp16 plane)
 GEMM_W_TILE_ROWS = 128     # rows per W image tile (128: occupancy kernel, 256: wide kernel)
 
 _DT = {np.dtype(np.float32): _lib.DT_F32, np.dtype(np.float64): _lib.DT_F64, np.dtype(np.int64): _lib.DT_I64}
@@ -47,7 +47,7 @@ class PackedWeights:
     """Owns an `ev2h_packed` handle (device allocation + the ev2h_weights view into it).  device "cpu": host-only pack (layout
     tests without a GPU)."""
 
-    def __init__(self, sd: dict, device, in_channels: int, precision: str = "f32", equalize: bool = True):
+    def __init__(self, sd: dict, device, in_channels: int, precision: str = "f32", equalize: bool = True, f16_families: int = 0):
         self.device = torch.device(device)
         self.in_channels = in_channels
         self.precision = precision
@@ -55,6 +55,8 @@ class PackedWeights:
         L = _lib.lib()
         descs, keep = tensor_descs(sd)
         flags = (_lib.PACK_EQUALIZE if equalize else _lib.PACK_UNEQUALIZED_OK)     # equalize=False is the explicit opt-out
+        if precision == "f16":
+            flags |= _lib.pack_f16_families(f16_families)      # 0 = all families (the mode's definition); a partial mask = mixed with f16x2
         self._handle = C.c_void_p()
         self._free = L.ev2h_packed_free
         if self.device.type == "cuda":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define EV2H_ABI_VERSION 7
+#define EV2H_ABI_VERSION 8
 
 typedef void* ev2h_stream_t; /* hipStream_t */
 
@@ -49,7 +49,15 @@ typedef void* ev2h_stream_t; /* hipStream_t */
  *          EV2H_W_EQUALIZED unless the caller opts out with EV2H_W_UNEQUALIZED_OK.  What no packer can see is a spread BETWEEN
  *          POINTS or between channels that only the data produces: ev2h_range_report counts, per tensor and window, the values
  *          that sit below 2^-17 of the maximum, and BF16X3 / F32 have no such limit;
- *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3).
+ *  BF16    operands rounded to bf16 (RNE), fp32 accumulation (BASELINE.json config 3's arithmetic as named; 8 mantissa bits).  NOT usable
+ *          on a trained checkpoint: 12-300 mm MPJPE against the exact-fp32 mode (profiles/r5_trained_precision_report.txt);
+ *  F16     [ABI 8] the REDUCED-PRECISION mode to use (config 3): every operand rounded to ONE fp16 plane (RNE, 11 mantissa bits: 8 x
+ *          finer than bf16) under F16X2's range machinery -- the same per-window / per-matrix powers of two from the same range
+ *          records, so nothing overflows and a value keeps its 11 bits down to 2^-28 of its window's maximum; ONE product per
+ *          multiply-add on v_mfma_f32_32x32x16_f16 (bf16's MFMA count and tile-image geometry); layer 1 of the set abstractions
+ *          that read raw feature rows keeps F16X2's three plane products (coordinate differences: 5 % of a strip's MFMAs).
+ *          Same equalisation contract as F16X2 (EV2H_W_EQUALIZED).  Measured on the optimiser-made checkpoints against the
+ *          exact-fp32 mode: profiles/r6_trained_precision_report.txt;
  * A few small layers run as exact fp32 fma chains in EVERY mode, because the matrix pipe has nothing to gain there: the one-row-per-
  * window layers (ev2h_gemm_desc.skinny), the folded attention product (ev2h_attn_sim_folded) and -- where they are still computed
  * (F32; EV2H_L1_TABLE=1) -- the K = 8 layer-1 tables of the raw cloud.  In the three plane modes ev2h_forward runs layer 1 of the set
@@ -58,8 +66,9 @@ typedef void* ev2h_stream_t; /* hipStream_t */
 #define EV2H_PREC_BF16 1
 #define EV2H_PREC_F16X2 2
 #define EV2H_PREC_BF16X3 3
+#define EV2H_PREC_F16 4      /* [ABI 8] also the `planes` code of this mode in ev2h_tile_geometry / ev2h_pack_*_image (ONE plane is stored) */
 
-/* Range records (EV2H_PREC_F16X2).  fp16 planes overflow at 65504, so every tensor that a contraction reads in F16X2 mode has a
+/* Range records (EV2H_PREC_F16X2, EV2H_PREC_F16).  fp16 planes overflow at 65504, so every tensor that a contraction reads in F16X2 mode has a
  * "range record": uint32 [groups], the IEEE-754 bit pattern of max|value| over each group of rows (a group = the rows of one
  * event window), maintained with integer atomicMax by whichever kernels write the tensor (y_amax / out_amax / amax arguments;
  * the caller zeroes the records first).  A consumer scales each group by an exact power of two derived from the record
@@ -69,6 +78,12 @@ typedef void* ev2h_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------------------- */
 int ev2h_abi_version(void);
+/* [ABI 8] sha256 (hex) of the sources this binary was built from -- every file of csrc/ and every header of include/, names and contents, as
+ * ev2hands_amd/build.py: source_hash() computes it -- and the extra compiler definitions of the build (EV2H_BUILD_DEFS; "" normally).
+ * A binding that ships next to the sources compares the hash when it loads the library (ev2hands_amd/_lib.py does and refuses a
+ * mismatch): the binary is git-ignored but copied between machines, so a stale one is otherwise silent. */
+const char* ev2h_source_hash(void);
+const char* ev2h_build_defs(void);
 const char* ev2h_last_error(void);
 /* One-time setup per device and host thread (raises dynamic-LDS limits of the big-tile kernels; creates the side stream
  * ev2h_forward forks onto).  Idempotent; ev2h_forward calls it itself.  Call it EARLY in a process that will create many HIP
@@ -89,6 +104,13 @@ int ev2h_set_side_stream(int enabled);
  * `stream` (a start-up probe, ~0.2 ms); not capturable.  Returns EV2H_ERR_ARG when the side stream is switched off
  * (EV2H_TWO_STREAMS=0 / creation failed): then there is nothing to probe and *ratio is set to 0.  [ABI 7] */
 int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio);
+/* [ABI 8] What shader clock is the chip running at RIGHT NOW?  Enqueues a one-wave kernel on `stream` that sleeps for ~spin_us
+ * microseconds and writes out_dev[0] = elapsed shader-clock cycles (s_memtime), out_dev[1] = elapsed ticks of the constant 100 MHz
+ * reference counter (s_memrealtime): clock in MHz = 100 * out_dev[0] / out_dev[1].  The matrix-pipe kernels are power-limited on
+ * real data (2.39 GHz idle boost -> ~1.65 GHz under a dense MFMA stream, profiles/r*_mfma_ceiling.txt), so a throughput figure taken
+ * over a fraction of a second can ride on a clock that a production run does not keep: a host launches this on a second stream
+ * while its workload runs and reports the clock next to the rate (bench.py `value_sustained`).  Asynchronous; capturable. */
+int ev2h_shader_clock_probe(ev2h_stream_t stream, int spin_us, unsigned long long* out_dev);
 /* sizeof() of the structs below, for binding-side layout checks: [gemm, sa, sa_module, weights, mano, outputs, fp, tensor_desc]. */
 void ev2h_struct_sizes(size_t out[8]);
 
@@ -269,7 +291,7 @@ typedef struct ev2h_fp_desc {
 int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream);
 
 /* Geometry of the host-packed weight tile images (W2s / W3s of ev2h_sa_desc and ev2h_fp_desc, Ws of ev2h_gemm_desc) for a chain
- * (C1, C2, C3) and `planes` operand planes (1 BF16, 2 F16X2, 3 BF16X3), straight from the kernels' compile-time configuration:
+ * (C1, C2, C3) and `planes` operand planes (1 BF16, 2 F16X2, 3 BF16X3; 4 = the F16 mode's code: one fp16 plane, BF16's geometry), straight from the kernels' compile-time configuration:
  * out = { T2 (32-row layer-2 tiles), C2P (layer-3 contraction length in the permuted order), RS2, RS3 (bytes per LDS row of a
  * W2 / W3 tile), TB2, TB3 (bytes per tile), GEMM RS (bytes per row of a dense W image tile), GEMM BK (k columns per tile),
  * LEFTOVER (0, or the 1..4 channels beyond the last full 32-channel tile whose plane products share MFMAs: the images then carry,
@@ -446,7 +468,16 @@ typedef struct ev2h_weights {
                                                     the channel equalisation (ev2h_pack_weights) multiplied fp1's
                                                     output by; every other consumer of that tensor has them folded into its columns */
     int flags;                                   /* EV2H_W_*                                            */
+    int f16_families;                            /* [ABI 8] precision == EV2H_PREC_F16 only: EV2H_FAM_* mask of the kernel families
+                                                    that run on ONE fp16 plane; the others run F16X2 (their images are packed
+                                                    accordingly; both read the same range records).  ev2h_pack_weights sets it.      */
 } ev2h_weights;
+/* kernel families of the F16 mode (ev2h_weights.f16_families; EV2H_PACK_F16_FAMILIES) */
+#define EV2H_FAM_SA 1             /* the fused set abstractions (enc.sa1, enc.sa2 + its layer-1 table GEMM, both regressors' sa1): 66 % of the MACs */
+#define EV2H_FAM_ROWS 2           /* the row chains: fp1 (+ its table GEMM) and the segmentation head                               */
+#define EV2H_FAM_QCONV 4          /* the k = 3 query convolution of both hands (16 % of the MACs)                                    */
+#define EV2H_FAM_DENSE 8          /* the other dense layers: sa3, fp3, fp2, the regressors' sa2                                      */
+#define EV2H_FAM_ALL 15
 #define EV2H_W_EQUALIZED 1        /* the hidden channels were equalised by ev2h_pack_weights (the F16X2 accuracy contract above)  */
 #define EV2H_W_UNEQUALIZED_OK 2   /* the caller knows its F16X2 weights are not equalised and wants them run anyway               */
 
@@ -482,6 +513,10 @@ typedef struct ev2h_tensor_desc {
 #define EV2H_PACK_EQUALIZE 1      /* step 2 above; what every F16X2 user wants                                                   */
 #define EV2H_PACK_HOST_ONLY 2     /* no device: the weights view points into the handle's HOST copy (layout tests without a GPU)  */
 #define EV2H_PACK_UNEQUALIZED_OK 4 /* sets EV2H_W_UNEQUALIZED_OK in the view (explicit opt-out of the F16X2 contract)             */
+/* [ABI 8] precision == EV2H_PREC_F16 only: which kernel families run on one fp16 plane (bits 8..11 of flags = an EV2H_FAM_* mask;
+ * the others are packed and run as F16X2).  No bits set = EV2H_FAM_ALL, the mode's definition; a partial mask is the "mixed" form
+ * (e.g. EV2H_PACK_F16_FAMILIES(EV2H_FAM_SA): only the fused set abstractions reduced). */
+#define EV2H_PACK_F16_FAMILIES(mask) (((mask) & 15) << 8)
 typedef struct ev2h_packed ev2h_packed;
 int ev2h_pack_weights(const ev2h_tensor_desc* tensors, int n, int in_channels, int precision, int flags, ev2h_packed** out);
 void ev2h_packed_free(ev2h_packed* p);
@@ -506,7 +541,7 @@ int ev2h_packed_weight_spread_count(const ev2h_packed* p);
 int ev2h_packed_weight_spread(const ev2h_packed* p, int i, const char** name, uint64_t counts[3]);
 /* The image builders on their own (operator-level callers of ev2h_sa_mlp_max / ev2h_fp_mlp / ev2h_gemm): W2 [C2][C1], W3 [C3][C2],
  * W [N][K] row-major float64 on the HOST; img* = caller's HOST buffers of ev2h_pack_*_bytes bytes; u* = the power-of-two factor
- * the planes were divided by (w2_unscale / w3_unscale / w_unscale).  planes: 1 BF16, 2 F16X2, 3 BF16X3. */
+ * the planes were divided by (w2_unscale / w3_unscale / w_unscale).  planes: 1 BF16, 2 F16X2, 3 BF16X3, 4 F16 (one fp16 plane of W / u). */
 int ev2h_pack_sa_image_bytes(int C1, int C2, int C3, int planes, size_t out[2]);
 int ev2h_pack_sa_images(const double* W2, const double* W3, int C1, int C2, int C3, int planes, void* img2, void* img3, float* u2,
                         float* u3);
@@ -570,6 +605,12 @@ int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, i
  * "rng.<tensor>" (e.g. "rng.l0", "rng.p1b") = the F16X2 range record of that tensor, "p1scale" = the storage scales of the
  * five layer-1 tables [5][B] (enc.sa1, enc.sa2, left, right, fp1; only enc.sa2 and fp1 are computed in the default F16X2 path). */
 const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);
+/* [ABI 8] The same with the element type: *elem_type = 0 for 4-byte elements (float32 / int32 / uint32, as documented per buffer),
+ * 1 for bf16 -- `count` then still counts VALUES, stored 2 bytes each.  Today that is "l0" after a forward of the calling thread in
+ * BF16 mode with the fused fp1 / segmentation-head / query-convolution forms (EV2H_L0_F32=1 keeps it float32): the one N-row,
+ * 256-wide tensor of the path is then written and read as bf16.  A debugger that reads "l0" as float32 in that mode compares garbage
+ * (ADVICE r5); ev2hands_amd's TEHNet.debug_buffer widens it. */
+const void* ev2h_workspace_buffer_ex(void* workspace, int B, int N, const char* name, size_t* count, int* elem_type);
 
 #ifdef __cplusplus
 }

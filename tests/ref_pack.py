@@ -83,7 +83,12 @@ def _up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-NS_OF = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3}     # operand planes per precision (csrc/planes.hpp)
+NS_OF = {"f32": 0, "bf16": 1, "f16x2": 2, "bf16x3": 3, "f16": 4}     # plane-mode code per precision (csrc/planes.hpp; 4 = ONE fp16 plane)
+
+
+def npl(ns: int) -> int:
+    """planes stored per operand (the code 4 = "f16" stores one)"""
+    return 1 if ns == 4 else ns
 
 
 def split_bf16_planes(a: np.ndarray, ns: int):
@@ -92,10 +97,12 @@ def split_bf16_planes(a: np.ndarray, ns: int):
     ns == 1: bf16, round to nearest even.  ns == 2: two fp16 planes, a = h + l with h = rne(a), l = rne(a - h).
     ns == 3: exact truncation split into three bf16 planes a = h + m + l (8 + 8 + 8 mantissa bits)."""
     x = np.ascontiguousarray(a, dtype=np.float32)
-    if ns == 2:
+    if ns in (2, 4):
         if x.size and float(np.abs(x).max()) >= 65504.0:
             raise ValueError("f16x2 needs |weight| < 65504 (fp16 range); use precision='bf16x3' or 'f32' for this checkpoint")
         h = x.astype(np.float16)
+        if ns == 4:                                    # "f16": the high plane alone
+            return [h.view(np.uint16)]
         l = (x - h.astype(np.float32)).astype(np.float16)
         return [h.view(np.uint16), l.view(np.uint16)]
     if ns == 1:
@@ -113,7 +120,7 @@ def plane_unscale(W: np.ndarray, ns: int) -> float:
     """Power of two u such that the planes are taken of W / u.  f16x2 only: fp16 has 5 exponent bits, so the low plane of a
     weight below 2^-3 is subnormal and small-magnitude layers lose accuracy (measured 2.6e-4 at |W| ~ 1e-4).  Dividing by
     u = 2^-k with max|W / u| in [2^13, 2^14) is exact and the kernels multiply the accumulated product by u (also exact)."""
-    if ns != 2:
+    if ns not in (2, 4):
         return 1.0
     m = float(np.abs(np.asarray(W, dtype=np.float64)).max()) if np.size(W) else 0.0
     if m == 0.0 or not np.isfinite(m):
@@ -162,10 +169,10 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     if left:
         assert ns == 2 and C2 - base == left and left <= 4
         p2[0][base + 8:base + 8 + left] = p2[1][base:base + left]        # rows 8.. of the high-plane image: the leftover rows' LOW plane
-    rs2 = ns * 64 + 16
+    rs2 = npl(ns) * 64 + 16
     img2 = np.zeros((C1 // 32, T2 * 32, rs2), dtype=np.uint8)
     for c in range(C1 // 32):
-        for s_ in range(ns):
+        for s_ in range(npl(ns)):
             blk = np.ascontiguousarray(p2[s_][:, 32 * c:32 * c + 32])               # [rows, 32] uint16
             img2[c, :, s_ * 64:(s_ + 1) * 64] = blk.view(np.uint8).reshape(T2 * 32, 64)
     # layer-3 contraction order follows the MFMA D layout of layer 2: position 32t+16m+8h+e <-> channel 32t+16m+4h+(e&3)+8(e>>2)
@@ -182,9 +189,9 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
         p3[0][:, base + 4:base + 8] = wh
         p3[0][:, base + 8:base + 12] = wl
         p3[0][:, base + 12:base + 16] = 0
-    rs3 = ns * C2P * 2 + 16
+    rs3 = npl(ns) * C2P * 2 + 16
     img3 = np.zeros((C3 // 32, 32, rs3), dtype=np.uint8)
-    for s_ in range(ns):
+    for s_ in range(npl(ns)):
         blk = p3[s_].view(np.uint8).reshape(C3 // 32, 32, C2P * 2)
         img3[:, :, s_ * C2P * 2:(s_ + 1) * C2P * 2] = blk
     mine = {"T2": T2, "C2P": C2P, "RS2": rs2, "RS3": rs3, "TB2": img2[0].size, "TB3": img3[0].size}
@@ -206,12 +213,12 @@ def gemm_bf16_w_image(W: np.ndarray, ns: int, rows: int = GEMM_W_TILE_ROWS):
     tn, nk = _up(N, rows) // rows, _up(K, 32) // 32
     Wp = _pad(W, tn * rows, nk * 32)
     planes = split_bf16_planes(Wp, ns)
-    rs = ns * 64 + 16
+    rs = npl(ns) * 64 + 16
     g = kernel_geometry(128, 128, 256, ns)
     if (g["GEMM_RS"], g["GEMM_BK"]) != (rs, 32):
         raise _lib.Ev2hError(f"dense W image geometry: pack.py builds rows of {rs} B x 32 k, the kernels expect {g['GEMM_RS']} B x {g['GEMM_BK']} k")
     img = np.zeros((tn, nk, rows, rs), dtype=np.uint8)
-    for s_ in range(ns):
+    for s_ in range(npl(ns)):
         blk = planes[s_].reshape(tn, rows, nk, 32).transpose(0, 2, 1, 3)         # [tn, nk, rows, 32] uint16
         img[:, :, :, s_ * 64:(s_ + 1) * 64] = np.ascontiguousarray(blk).view(np.uint8).reshape(tn, nk, rows, 64)
     return img.reshape(-1), u
@@ -393,6 +400,8 @@ class PackedWeights:
         self.struct = _lib.Weights()
         w = self.struct
         w.precision = _lib.PREC[precision]
+        if precision == "f16":
+            w.f16_families = _lib.FAM_ALL
         F = fold_checkpoint(sd)
         # exact power-of-two channel equalisation (equalize_channels): applied in EVERY precision mode, so that all modes run the
         # same network representation (the exact-fp32 results do not change by a bit)

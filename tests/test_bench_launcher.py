@@ -32,6 +32,10 @@ def test_direct_invocation_launches_its_own_ranks():
     assert d["gathered_rows"] == 6 and d["gathered_rank_ids"] == [0, 1]       # both shards arrived through the all-gather
     assert d["value"] > 0 and d["scaling"] == "weak" and d["unit"] == "event-windows/s"
     assert "roofline" not in d and "cpu_baseline" not in d                     # a stub line can never pass for a measurement
+    # ... but it lists what the REAL path prints at this world size (bench.py: expected_line_keys, checked by the real run itself
+    # as `line_complete`): a multi-GPU line carries the roofline, the CPU baseline and the sustained leg like the 1-GPU line does
+    for k in ("roofline", "roofline_second", "hbm", "cpu_baseline", "value_sustained", "multi_gpu_selfcheck", "ms_per_step_per_rank", "line_complete"):
+        assert k in d["would_emit"], k
 
 
 def test_eight_ranks_as_the_driver_will_run_it():
@@ -42,6 +46,17 @@ def test_eight_ranks_as_the_driver_will_run_it():
     d = _line(p.stdout)
     assert d["n_gpus"] == 8 and d["config"]["world_size_seen"] == 8 and d["config"]["global_batch"] == 16
     assert d["gathered_rows"] == 16 and d["gathered_rank_ids"] == list(range(8))
+    for k in ("roofline", "cpu_baseline", "value_sustained", "multi_gpu_selfcheck"):           # the first SCALE line must be gradeable
+        assert k in d["would_emit"], k
+
+
+def test_expected_line_keys_follow_the_switches():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse(["--gpus", "8", "--no-cpu-baseline", "--no-sustained"])
+    keys = bench.expected_line_keys(8, a)
+    assert "cpu_baseline" not in keys and "value_sustained" not in keys and "roofline" in keys and "multi_gpu_selfcheck" in keys
+    assert bench.newest_profile("r*_mfma_ceiling.txt") is not None            # roofline.sustained_source names the newest round's file
 
 
 def test_under_torch_distributed_run_exactly_as_the_driver_launches_it():

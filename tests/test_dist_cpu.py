@@ -174,3 +174,82 @@ def test_pack_unpack_roundtrip():
     assert torch.equal(back["class_logits"], out["class_logits"])
     assert torch.equal(back["right"]["vertices"], out["right"]["vertices"])
     assert evdist.pack_outputs(out).shape[1] == evdist.packed_width(N)
+
+
+class _FakeNet:
+    """stands in for TEHNetWrapper on CPU: `.net(xyz, hands, rows=)` writes one packed row per window (value = f(window id)), as
+    ev2h_forward does through ev2h_outputs' window strides; records the fps_init it was handed"""
+
+    def __init__(self, N):
+        self.N, self.hands, self.net, self.seen_inits = N, None, self, []
+        self.fps_init = None
+
+    def __call__(self, xyz, hands, rows=None, ws=None):
+        ids = xyz[:, 0, 0].long().tolist()
+        rows.copy_(torch.cat([evdist.pack_outputs(_fake_outputs(i, i + 1, self.N)) for i in ids], 0))
+        self.seen_inits.append(self.fps_init)
+        self.fps_init = None
+        return evdist.unpack_outputs(rows, self.N)
+
+
+def _worker_pipeline_forward(rank, world, port, gB, N, q):
+    """[r6] GatherPipeline.forward: ONE call per step (forward into the next buffer + asynchronous gather), results one step late"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = evdist.shard_range(gB, rank, world)
+    net = _FakeNet(N)
+    pipe = evdist.GatherPipeline(N, gB, "cpu", depth=2, net=net)
+    ok, prev, posted = True, None, []
+    for step in range(4):
+        xyz = (torch.arange(lo, hi, dtype=torch.float32) + 100 * step).view(-1, 1, 1).expand(hi - lo, 4, N).contiguous()
+        cur = pipe.forward(xyz, fps_init=[step] * 4, post=lambda out: posted.append(int(out["class_logits"][0, 0, 0])))
+        if prev is not None:
+            st, h = prev
+            full, want = h.result(), _fake_outputs(100 * st, gB + 100 * st, N)
+            ok = ok and torch.equal(full["class_logits"], want["class_logits"]) and torch.equal(full["left"]["vertices"], want["left"]["vertices"])
+        prev = (step, cur)
+    pipe.drain()
+    ok = ok and net.seen_inits == [[s] * 4 for s in range(4)] and posted == [lo + 100 * s for s in range(4)]
+    try:                                                   # inflight mode needs the net (and a GPU: slot streams)
+        evdist.GatherPipeline(N, gB, "cpu", inflight=2)
+        ok = False
+    except ValueError as e:
+        ok = ok and "needs net=" in str(e)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gather_pipeline_forward_world2():
+    world, N, gB = 2, 64, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipeline_forward, args=(r, world, port, gB, N, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_transport_is_chosen_by_capability_not_by_name():
+    """a gloo group cannot move device memory (host-staged transport for CUDA buffers, with ONE warning); the decision is
+    asked of the group (`_group_moves_device_memory`), so a group whose backend string is not literally "nccl" but which has a
+    device backend is not silently sent down the host-staged path"""
+    class _G:                                              # a group with a device backend under another name string
+        def _get_backend(self, device):
+            class ProcessGroupNCCL:
+                pass
+            return ProcessGroupNCCL()
+    assert evdist._group_moves_device_memory(_G())
+
+    class _H:
+        def _get_backend(self, device):
+            raise RuntimeError("no backend for cuda")
+    import unittest.mock as mock
+    with mock.patch.object(dist, "get_backend_config", lambda g: "cpu:gloo"), mock.patch.object(dist, "get_backend", lambda g: "gloo"):
+        assert not evdist._group_moves_device_memory(_H())
+    with mock.patch.object(dist, "get_backend_config", lambda g: "cpu:gloo,cuda:nccl"):
+        assert evdist._group_moves_device_memory(_H())

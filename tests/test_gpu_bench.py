@@ -54,13 +54,24 @@ def test_bench_forced_single_rank_rccl_path():
     old = os.environ.get(env_key)
     os.environ[env_key] = "1"
     try:
-        j = _run("--no-host-io")
+        j = _run("--no-host-io", "--sustained-seconds", "1.2")
     finally:
         if old is None:
             os.environ.pop(env_key, None)
         else:
             os.environ[env_key] = old
     assert j["config"]["backend"] == "nccl (RCCL)" and j["config"]["world_size_seen"] == 1
+    # [r6] the line of the multi-GPU code path is complete by its own definition (bench.py: expected_line_keys) ...
+    assert j["line_complete"] is True, j["line_complete"]
+    # ... its roofline says where the traffic figure comes from (no PMC child run here: the committed profile) ...
+    assert j["roofline"]["traffic_kind"] in ("committed", None) and "mfma_ceiling" in j["roofline"]["sustained_source"]
+    if j["roofline"]["traffic"] is not None:
+        assert "not measured in this run" in j["roofline"]["traffic_source"]
+    # ... and the sustained leg ran for >= 1 s with the shader clock observed during it
+    vs = j["value_sustained"]
+    assert vs["seconds"] >= 1.0 and 0.5 < vs["ratio_to_value"] < 1.5 and vs["shader_clock_mhz"]["samples"] >= 8, vs
+    assert 500.0 < vs["shader_clock_mhz"]["median"] < 3000.0 and 500.0 < vs["shader_clock_mhz_idle"] < 3000.0, vs
+    assert len(vs["shader_clock_mhz_median_per_rank"]) == 1
     sc = j["multi_gpu_selfcheck"]
     assert sc["gather_ms"] >= 0.0 and len(sc["two_stream_gain_per_rank"]) == 1
     assert abs(j["ms_per_step_per_rank"]["max"] - j["ms_per_step"]) <= 0.05 * j["ms_per_step"]
@@ -92,3 +103,14 @@ def test_bench_live_traffic_at_n8192_names_the_query_convolution(precision):
     t1, t2 = j["roofline"]["traffic"], j["roofline_second"]["traffic"]
     assert t1 is not None and 20e6 < t1 < 400e6, t1
     assert t2 is not None and 1e6 < t2 < 400e6, t2
+
+
+def test_bench_line_carries_the_cpu_baseline_on_the_multi_gpu_path():
+    """the forced 1-rank RCCL path WITH the CPU leg (bounded to a few seconds): the key a SCALE line was missing"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EV2H_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "1", "--batch", "8", "--no-legs", "--no-latency", "--no-traffic",
+           "--no-host-io", "--no-second-site", "--no-selfcheck", "--sustained-seconds", "0.3", "--cpu-seconds", "3"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert j["line_complete"] is True and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1

@@ -89,24 +89,34 @@ def _rank(rank, world, port, gB, N, C, precision, q):
             res["last_gather_equals_unsharded"] = bool(ok)
             pipe.drain()
 
-            # the same with two forwards in flight per rank (ev2hands_amd/inflight.py; config 5 as 16-window shards): forward i on
-            # stream i mod 2 with its own workspace, the gather of step i issued from that stream right behind its forward
-            from ev2hands_amd.inflight import InflightForward
-            infl = InflightForward(net, depth=2)
-            pend2 = []
-            for step in range(4):
-                net.net.fps_init = evdist.shard_fps_inits(inits, lo, hi)
-                box = []
-                infl.submit(xyz[lo:hi], rows=pipe.rows(), post=lambda out: box.append(pipe.submit()))
-                pend2.append(box[0])
-            infl.drain()
-            got = pend2[3].result()
+            # the same with two forwards in flight per rank, as ONE call per step [r6]: GatherPipeline(inflight=2).forward -- forward i on
+            # slot stream i mod 2 with its own workspace, the gather of step i issued from that stream right behind its forward, the
+            # wait for the gather that last read the buffer on the slot's stream too (config 5 as 16-window shards)
+            pipe2 = evdist.GatherPipeline(N, gB, dev, depth=2, inflight=2, net=net)
+            my_inits = evdist.shard_fps_inits(inits, lo, hi)
+            pend2 = [pipe2.forward(xyz[lo:hi], fps_init=my_inits) for _ in range(2)]
+            oks = []
+            for step in range(2, 6):                         # results consumed one step late, buffers and slots reused
+                got = pend2[step - 1].result()
+                ok = torch.equal(got["class_logits"], want["class_logits"])
+                for side in ("left", "right"):
+                    for k in want[side]:
+                        ok = ok and torch.equal(got[side][k], want[side][k])
+                oks.append(bool(ok))
+                pend2.append(pipe2.forward(xyz[lo:hi], fps_init=my_inits))
+            try:                                             # the generation guard holds in this mode too
+                pend2[0].result()
+                oks.append(False)
+            except RuntimeError:
+                oks.append(True)
+            pipe2.drain()
+            got = pend2[-1].result()
             ok = torch.equal(got["class_logits"], want["class_logits"])
             for side in ("left", "right"):
                 for k in want[side]:
                     ok = ok and torch.equal(got[side][k], want[side][k])
-            res["inflight_gather_equals_unsharded"] = bool(ok)
-            pipe.drain()
+            res["inflight_gather_equals_unsharded"] = bool(ok) and all(oks)
+            del pipe2
 
             # the per-rank two-stream self-check of bench.py, with both ranks hammering the same GPU
             L = _lib.lib()
@@ -145,7 +155,7 @@ def _rank(rank, world, port, gB, N, C, precision, q):
         q.put((rank, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
 
 
-@pytest.mark.parametrize("gB,N,C,precision", [(6, 2048, 4, "f16x2"), (5, 1024, 5, "bf16x3")])
+@pytest.mark.parametrize("gB,N,C,precision", [(6, 2048, 4, "f16x2"), (5, 1024, 5, "bf16x3"), (32, 8192, 4, "f16x2"), (6, 2048, 4, "f16")])
 def test_two_ranks_on_one_gpu_gather_equals_unsharded(gB, N, C, precision):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -176,3 +186,69 @@ def test_two_ranks_on_one_gpu_gather_equals_unsharded(gB, N, C, precision):
         assert out[r]["inflight_gather_equals_unsharded"], out
         assert out[r]["single_stream_rows_equal_two_stream_rows"], out
         assert 0.3 < out[r]["two_stream_gain"] < 3.0, out          # a report (two processes share the GPU here), not a bar
+
+
+def _rank_auto(rank, world, port, q):
+    """precision = "auto" under a process group: rank 1's verification is made to fail (tolerance 0); the decision is collective"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", ERPC="0")
+        os.environ.pop("EV2H_PRECISION", None)
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+
+        from ev2hands_amd import _lib, dist as evdist, synth
+        from ev2hands_amd.model import TEHNetWrapper
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        _lib.lib().ev2h_init()
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        net = TEHNetWrapper(dev, mano_assets={s: synth.synth_mano_assets(s, 3) for s in ("left", "right")})
+        net.load_state_dict(synth.synth_state_dict(4, 3), strict=True)
+        net.eval()
+        assert net.net.precision == "auto"
+        if rank == 1:
+            net.net.AUTO_TOLERANCE = 0.0                       # this rank's shard "fails" the check
+        gB, N = 4, 512
+        xyz = synth.synth_cloud("E", gB, 4, N, 12).to(dev)
+        inits = synth.fps_inits(gB, N, 12)
+        lo, hi = evdist.shard_range(gB, rank, world)
+        net.net.fps_init = evdist.shard_fps_inits(inits, lo, hi)
+        with torch.no_grad():
+            net(xyz[lo:hi])
+        torch.cuda.synchronize()
+        rep = net.net.auto_report
+        res = {"chose": net.net.effective_precision(), "ok": rep["ok"], "ok_this_rank": rep["ok_this_rank"], "ranks": rep.get("ranks")}
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, res, None))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+def test_auto_precision_decision_is_collective():
+    """under torch.distributed every rank verifies f16x2 on its own shard and the group takes the MINIMUM -- one rank whose
+    check fails sends ALL ranks to bf16x3 (a lone bf16x3 rank would break sharded == unsharded and stall every all-gather)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_auto, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    try:
+        for _ in range(2):
+            rank, res, err = q.get(timeout=600)
+            assert err is None, f"rank {rank}: {err}"
+            out[rank] = res
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert out[0]["ok_this_rank"] is True and out[1]["ok_this_rank"] is False, out
+    assert out[0]["chose"] == out[1]["chose"] == "bf16x3" and out[0]["ok"] is False and out[0]["ranks"] == 2, out

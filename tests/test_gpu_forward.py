@@ -196,6 +196,96 @@ def test_bf16_mode_on_trained_weights(path):
     assert all(np.isfinite(v) for r in rep for v in r)
 
 
+# [r6] What the ONE-PLANE fp16 mode ("f16": BASELINE config 3's throughput arithmetic that is usable on a trained network) must hold on
+# the optimiser-made checkpoints, against the outputs the REFERENCE recorded (tests/golden/trained_*.npz; two windows each, the worse
+# hand), per fixture kind: (argmax agreement >=, logits rel <=, MPJPE mm <=, root-relative MPJPE mm <=, params rel <=).
+# Measured (this test's printout, profiles/r6_gpu_tests.txt):   f16                                   plain bf16
+#   E_c4_n2048   argmax 1.0000  logits 1.9e-3  MPJPE 12.5 mm  root-relative 0.25 mm  params 1.9e-2 | 0.9963  2.5e-2   71.6   1.97  1.1e-1
+#   E_c4_n8192          0.9995         9.0e-4         0.15                  0.005           3.9e-4 | 0.9946  6.2e-3    0.65  0.02  4.8e-3
+#   E_c5_n2048          0.9988         2.6e-3         7.0                   0.088           4.1e-3 | 0.9888  2.7e-2  271     3.67  2.4e-1
+#   U_c4_n2048          1.0000         1.1e-3        61                     4.6             3.3e-3 | 0.9990  8.3e-3  763    38     5.6e-2
+# The bounds are 2.5-3 x the measured worst.  Root-relative MPJPE is the reference's own metric (evaluate_ev2hands_r.py:43-54); the
+# absolute figure is dominated by the regressed TRANSLATION, which passes through the regression head's Linear -> ReLU -> BatchNorm
+# with collapsed running variances (fold scale 316, DESIGN.md "trained checkpoints") -- any upstream rounding is amplified there, in
+# every mode, in proportion to its size (f16x2: 0.001-0.04 mm).  E = event-like clouds (what the network was trained on); U = uniform
+# clouds, far outside its training distribution (one class everywhere, poses at the edge of the regressor's range): the looser row.
+F16_BOUNDS = {"E": (0.998, 6e-3, 32.0, 0.7, 5e-2), "U": (0.9995, 4e-3, 170.0, 13.0, 1.5e-2)}
+
+
+def _reduced_mode_metrics(path, precision):
+    import trained_ckpt
+    g = np.load(path)
+    B, C, N, seed = [int(v) for v in g["meta"]]
+    net, _sd, _assets = make_net(C, seed, precision=precision, sd=trained_ckpt.trained_state_dict(C))
+    net.net.fps_init = [torch.from_numpy(g["fps_init"][i].astype(np.int64)) for i in range(4)]
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["xyz"]).cuda())
+    torch.cuda.synchronize()
+    agree = float((out["class_logits"].argmax(1).cpu().numpy() == g["argmax"]).mean())
+    lerr = rel(out["class_logits"], g["class_logits"])
+    mp, mpr, prm = [], [], []
+    for s in ("left", "right"):
+        a, b = out[s]["j3d"].cpu().double(), torch.from_numpy(g[f"unpinned.{s}.j3d"]).double()
+        mp.append(float((a - b).norm(dim=-1).mean()) * 1e3)
+        mpr.append(float(((a - a[:, :1]) - (b - b[:, :1])).norm(dim=-1).mean()) * 1e3)       # evaluate_ev2hands_r.py:43-54
+        prm.append(rel(torch.cat([out[s][k] for k in ("global_orient", "hand_pose", "betas", "transl")], 1), g[s + ".params"]))
+    for name, buf in (("sa1.fps", "fps1"), ("sa2.fps", "fps2"), ("sa1.group2", "gidx1_2"), ("sa2.group1", "gidx2_1")):      # selections stay fp32: exact in every mode
+        assert np.array_equal(net.net.debug_buffer(buf, torch.int32).cpu().numpy().reshape(g[name].shape), g[name].astype(np.int32)), name
+    return {"argmax": agree, "logits": lerr, "mpjpe_mm": max(mp), "rr_mpjpe_mm": max(mpr), "params": max(prm)}
+
+
+@pytest.mark.parametrize("path", TRAINED, ids=[os.path.basename(p)[:-4] for p in TRAINED])
+def test_f16_mode_on_trained_weights_is_bounded(path):
+    """the reduced-precision mode gets an accuracy CONTRACT on weights that came out of an optimiser -- bounded, not
+    just finite -- and plain bf16 stays next to it as the comparison (it is 4-10 x further out on every metric)."""
+    _need_gpu()
+    kind = os.path.basename(path).split("_")[1]
+    m = _reduced_mode_metrics(path, "f16")
+    b = _reduced_mode_metrics(path, "bf16")
+    print(f"reduced modes on {os.path.basename(path)} vs the reference-run fixture:\n   f16 : " + ", ".join(f"{k} {v:.4g}" for k, v in m.items())
+          + "\n   bf16: " + ", ".join(f"{k} {v:.4g}" for k, v in b.items()))
+    agree, lerr, mp, mpr, prm = F16_BOUNDS[kind]
+    assert m["argmax"] >= agree and m["logits"] <= lerr and m["mpjpe_mm"] <= mp and m["rr_mpjpe_mm"] <= mpr and m["params"] <= prm, m
+    assert m["logits"] < 0.5 * b["logits"] and m["mpjpe_mm"] < 0.5 * b["mpjpe_mm"] and m["argmax"] >= b["argmax"], (m, b)      # 11 mantissa bits against 8
+
+
+def test_f16_family_masks():
+    """ev2h_weights.f16_families: the F16 mode with a partial family mask runs the other families as F16X2 (same range records,
+    images packed per family).  Every mask runs; reducing only the k = 3 query convolution leaves the logits at fp32 class (the
+    segmentation head does not read it) and is closer to the exact-fp32 mode than reducing everything."""
+    _need_gpu()
+    import trained_ckpt
+    from ev2hands_amd import _lib
+    C, seed, B, N = 4, 61, 4, 2048
+    xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    net, _sd, _assets = make_net(C, seed, precision="f32", sd=trained_ckpt.trained_state_dict(C))
+
+    def run(prec, mask=0):
+        net.net.precision, net.net.f16_families = prec, mask
+        net.net.fps_init = inits
+        with torch.no_grad():
+            o = net(xyz)
+        return o["class_logits"].clone(), torch.cat([o[s][k] for s in ("left", "right") for k in ("global_orient", "hand_pose", "betas", "transl")], 1).clone()
+
+    ref = run("f32")
+    full = run("f16")
+    assert net.net.packed(xyz.device).struct.f16_families == _lib.FAM_ALL
+    same = run("f16", _lib.FAM_ALL)
+    assert torch.equal(full[0], same[0]) and torch.equal(full[1], same[1])
+    errs = {}
+    for mask in (_lib.FAM_SA, _lib.FAM_ROWS, _lib.FAM_QCONV, _lib.FAM_DENSE, _lib.FAM_SA | _lib.FAM_QCONV):
+        got = run("f16", mask)
+        assert net.net.packed(xyz.device).struct.f16_families == mask
+        errs[mask] = (rel(got[0], ref[0]), rel(got[1], ref[1]))
+    efull = (rel(full[0], ref[0]), rel(full[1], ref[1]))
+    print("f16 family masks, (logits, params) rel vs f32:", {k: (f"{a:.1e}", f"{b:.1e}") for k, (a, b) in errs.items()}, "all:", tuple(f"{v:.1e}" for v in efull))
+    assert errs[_lib.FAM_QCONV][0] < 2e-5                      # the logits never see the query convolution
+    assert errs[_lib.FAM_QCONV][1] < efull[1]
+    assert all(1e-7 < e[1] < 0.2 for e in errs.values())
+    net.net.f16_families = 0
+
+
 def run_reference_fixture(path, precision, sd=None):
     _need_gpu()
     g = np.load(path)
@@ -873,3 +963,28 @@ def test_bf16_l0_storage_agrees_with_fp32_storage(tmp_path):
     worst = max(rel(a[k], b[k]) for k in a if k not in ("gidx", "nn"))
     print(f"bf16: l0 stored as bf16 vs fp32: worst relative difference {worst:.2e}")
     assert 0.0 < worst < 3e-2
+
+
+def test_debug_buffer_knows_what_l0_holds_in_bf16_mode():
+    """in BF16 mode the workspace's "l0" holds bf16 values (2 bytes each); ev2h_workspace_buffer_ex reports the element
+    type and TEHNet.debug_buffer widens it -- read as float32 bytes (what the old accessor implied) it was garbage."""
+    _need_gpu()
+    C, seed, B, N = 4, 17, 2, 1024
+    xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
+    inits = synth.fps_inits(B, N, seed)
+    l0 = {}
+    for prec in ("f32", "bf16", "f16x2"):
+        net, _sd, _assets = make_net(C, seed, precision=prec)
+        net.net.fps_init = inits
+        with torch.no_grad():
+            net(xyz)
+        torch.cuda.synchronize()
+        l0[prec] = net.net.debug_buffer("l0").view(B, N, 256).cpu()
+        if prec == "bf16":
+            with pytest.raises(TypeError):
+                net.net.debug_buffer("l0", torch.int32)
+    assert l0["bf16"].dtype == torch.float32 and torch.isfinite(l0["bf16"]).all()
+    assert rel(l0["f16x2"], l0["f32"]) < 1e-5
+    e = rel(l0["bf16"], l0["f32"])
+    print(f"bf16-stored l0 against the exact-fp32 mode's: {e:.2e}")
+    assert 1e-5 < e < 2e-2

@@ -232,3 +232,34 @@ def test_side_stream_probe_sees_two_concurrent_streams():
             _lib.side_stream_probe(50)
     finally:
         _lib.lib().ev2h_set_side_stream(prev)
+
+
+@pytest.mark.parametrize("log2_spread", [6.0, 6.5, 7.0, 7.5])
+def test_auto_mode_in_the_band_between_its_threshold_and_a_gross_failure(log2_spread):
+    """the guard tests covered passes (<= 2e-5) and gross failures (>= 6e-4) only.  Un-equalised checkpoints with hidden
+    channels 2^12 ... 2^15 apart put the f16x2-vs-bf16x3 disagreement INSIDE that band: whatever it measures, "auto" must keep f16x2
+    exactly when the disagreement is within AUTO_TOLERANCE (and the argmax identical), fall back otherwise, and the forward it then
+    runs must hold the parity bar against the oracle either way."""
+    _need_gpu()
+    C, N, B, seed = 4, 512, 2, 9
+    net, sd0, assets = make_net(C, seed, precision="auto")
+    sd = sc.rescale_channels(sd0, log2_spread, seed)
+    net.load_state_dict(sd, strict=True)
+    net.net.equalize = False
+    xyz, inits = synth.synth_cloud("E", B, C, N, seed), synth.fps_inits(B, N, seed)
+    ref, trace = run_oracle(sd, assets, xyz, inits)
+    net.net.fps_init = inits
+    with torch.no_grad():
+        out = net(xyz.cuda())
+    rep = net.net.auto_report
+    chose = net.net.effective_precision()
+    print(f"un-equalised, channels 2^+-{log2_spread}: f16x2 vs bf16x3 max rel {rep['max_rel']:.2e}, argmax agreement {rep['argmax_agreement']:.5f} -> auto chose {chose}")
+    keep = rep["max_rel"] <= net.net.AUTO_TOLERANCE and rep["argmax_agreement"] == 1.0
+    assert chose == ("f16x2" if keep else "bf16x3") and rep["ok"] == keep
+    assert rep["max_rel"] < 5e-3                                   # (the band and its neighbourhood: not the gross-failure regime)
+    if chose == "f16x2":
+        check_against(out, net, ref, trace, B, N, tol=max(1e-4, 2.5 * net.net.AUTO_TOLERANCE))       # accepted: within 5e-5 of bf16x3, which is within ~2e-5 of the reference
+    else:
+        check_against(out, net, ref, trace, B, N)
+    # the forward after the decision reuses the image packed during it (no third pack)
+    assert net.net._packed_spare is None and net.net._packed.precision == chose

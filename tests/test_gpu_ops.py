@@ -99,7 +99,7 @@ def test_three_nn_interp(kind, N1, N2, D):
     assert rel(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2), ("f16", 4e-3)])
 @pytest.mark.parametrize("kind,B,N1,N2,mag", [("E", 2, 2048, 512, 1.0), ("U", 3, 1000, 512, 1.0), ("E", 1, 130, 128, 1.0),
                                               ("E", 2, 2048, 512, 3e-5), ("E", 2, 2048, 512, 4e5)])
 def test_feature_propagation_fused(kind, B, N1, N2, mag, precision, tol):
@@ -116,7 +116,7 @@ def test_feature_propagation_fused(kind, B, N1, N2, mag, precision, tol):
     f2[B - 1] *= 0.01                                         # windows of different magnitude in one batch
     Ws = [torch.from_numpy(synth.hash_normal(f"W{i}", (o, k), 6 + i) / np.sqrt(k)).float() for i, (o, k) in enumerate(((128, 128), (128, 128), (256, 128)))]
     bs = [torch.from_numpy(synth.hash_normal(f"b{i}", (o,), 9 + i) * 0.1).float() * mag for i, o in enumerate((128, 128, 256))]
-    ranges = precision == "f16x2"
+    ranges = precision in ("f16x2", "f16")         # the fp16-plane modes: range records
     x_amax = out_amax = None
     if ranges:
         x_amax = ops.range_record(B, "cuda")
@@ -138,7 +138,7 @@ def test_feature_propagation_fused(kind, B, N1, N2, mag, precision, tol):
         assert torch.equal(ops.range_values(out_amax).cpu(), out.abs().amax(dim=(1, 2)).cpu())
 
 
-@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("f16x2", 6e-6), ("bf16x3", 6e-6), ("bf16", 3e-2), ("f16", 4e-3)])
 @pytest.mark.parametrize("B,N,mag", [(2, 2048, 1.0), (3, 1000, 1.0), (1, 130, 1.0), (2, 512, 1e-5), (2, 512, 3e6)])
 def test_row_chain_segmentation_head(B, N, mag, precision, tol):
     """ev2h_fp_mlp on plain rows (both classifier layers in one kernel, logits point-major and channel-major) against float64;
@@ -153,7 +153,7 @@ def test_row_chain_segmentation_head(B, N, mag, precision, tol):
     b3 = torch.from_numpy(synth.hash_normal("b3", (4,), 25) * 0.1).float() * mag
     ref = torch.relu(X.double() @ W2.double().T + b2.double()) @ W3.double().T + b3.double()
     xa = oa = None
-    if precision == "f16x2":
+    if precision in ("f16x2", "f16"):
         xa = ops.range_record(B, "cuda")
         xa.copy_(X.abs().amax(dim=(1, 2)).view(torch.int32).cuda())
         oa = ops.range_record(B, "cuda")
@@ -182,7 +182,7 @@ GEMM_CASES = [
 
 
 @pytest.mark.parametrize("precision,tol,wrows", [("f32", 2e-6, 128), ("bf16x3", 3e-6, 128), ("bf16x3", 3e-6, 256), ("f16x2", 6e-6, 128), ("f16x2", 6e-6, 256), ("bf16", 2e-2, 128),
-                                                 ("bf16", 2e-2, 256)])
+                                                 ("bf16", 2e-2, 256), ("f16", 3e-3, 128), ("f16", 3e-3, 256)])
 @pytest.mark.parametrize("M,N,K,relu,post,taps,rowmax,group", GEMM_CASES)
 def test_gemm(M, N, K, relu, post, taps, rowmax, group, precision, tol, wrows):
     _need_gpu()
@@ -248,9 +248,10 @@ def test_gemm_skinny_rows_are_windows(M, N, K, relu, post):
     assert torch.equal(one[0], outs["f32"][M // 2])
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x2", 4e-6), ("f16", 2e-3)])
 @pytest.mark.parametrize("wscale", [1e-2, 1e-4, 1e-6, 30.0])
 @pytest.mark.parametrize("N", [256, 22])
-def test_f16x2_weight_magnitude_does_not_matter(wscale, N):
+def test_f16x2_weight_magnitude_does_not_matter(wscale, N, precision, tol):
     """fp16 has 5 exponent bits: without the exact power-of-two pre-scaling of the weight planes (pack.py: plane_unscale) the low
     plane of small weights is subnormal and the error reaches 2.6e-4 at |W| ~ 1e-4.  N = 22: the head layers, whose W is split
     in the kernel (no plane image)."""
@@ -261,8 +262,8 @@ def test_f16x2_weight_magnitude_does_not_matter(wscale, N):
     W = (torch.from_numpy(synth.hash_normal("W", (N, K), 32) / np.sqrt(K)).float() * wscale).cuda()
     b = (torch.from_numpy(synth.hash_normal("b", (N,), 33)).float() * wscale).cuda()
     ref = X.double() @ W.double().t() + b.double()
-    got = ops.dense(X, W, b, False, precision="f16x2")
-    assert rel(got, ref) < 4e-6
+    got = ops.dense(X, W, b, False, precision=precision)
+    assert rel(got, ref) < tol
 
 
 @pytest.mark.parametrize("wscale", [1e-2, 1e-3])
@@ -294,10 +295,52 @@ def test_sa_f16x2_small_weights(wscale):
     assert rel(got, ref) < 8e-6
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x2", 8e-6), ("f16", 3e-3)])
+@pytest.mark.parametrize("mag", [1.0, 1e3, 1e6, 1e-4])
+def test_sa_mlp_max_table_form_with_range_records(mag, precision, tol):
+    """[r6] The TABLE form of the fused set abstraction (enc.sa2's) with the fp16-plane range arguments on, at layer-1 magnitudes
+    1e-4 ... 1e6 (table, relative-xyz weights and the next layer's columns scaled together; the function is unchanged): the table
+    arrives stored with its power of two (p1_scale), the kernel's layer 1 must produce s1 H1 without leaving the fp16 range.
+    F16 runs layer 1 on the matrix pipe with launch-constant powers of two on the weight side (SaBP::a1x) -- the 1e6 case caught
+    them being computed before the range arguments were set (a1x = 1: weights of 1e6 in an fp16 plane)."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    C1, C2, C3, K, B, Npts, S = 128, 128, 256, 64, 2, 512, 24
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, 77) * sc).float()
+    P1 = g("P1", (B, Npts, C1), mag)
+    xyz = cloud_xyz("U", B, Npts, 45)
+    ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), 78)).int()
+    W1x = g("W1x", (C1, 3), 0.5 * mag)
+    W2, b2 = g("W2", (C2, C1), C1 ** -0.5 / mag), g("b2", (C2,), 0.1)
+    W3, b3 = g("W3", (C3, C2), C2 ** -0.5), g("b3", (C3,), 0.1)
+    bi = torch.arange(B).view(B, 1, 1)
+    rows = P1.double()[bi, gidx.long()]
+    dxyz = (xyz[bi, gidx.long()] - ctr.view(B, S, 1, 3)).double()
+    h1 = (rows + dxyz @ W1x.double().t()).clamp_min(0)
+    h2 = (h1 @ W2.double().t() + b2.double()).clamp_min(0)
+    ref = (h2 @ W3.double().t() + b3.double()).clamp_min(0).max(2)[0]
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = W1x
+    dmax = float(dxyz.abs().max()) * 1.0001
+    bound = P1.abs().amax((1, 2)) + float(W1x.abs().sum(1).max()) * dmax            # what the table's producer bounds layer 1 by
+    sc_ = torch.exp2(torch.floor(torch.log2(32768.0 / bound)))
+    sc_ = torch.where(sc_ * bound >= 32768.0, sc_ / 2, sc_)
+    P1s = (P1 * sc_.view(B, 1, 1)).contiguous()                                    # exact: powers of two
+    p1_amax = ops.range_record(B, "cuda")
+    p1_amax.view(torch.float32).copy_(P1s.abs().amax((1, 2)))
+    out_amax = ops.range_record(B, "cuda")
+    got = ops.sa_mlp_max(P1s.cuda(), ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2.cuda(), b2.cuda(), W3.cuda(),
+                         b3.cuda(), C2, precision, p1_scale=sc_.cuda(), p1_amax=p1_amax, dmax=dmax, out_amax=out_amax)
+    err = rel(got, ref)
+    print(f"table form with range records, {precision}, layer-1 magnitude {mag:g}: rel err {err:.2e}")
+    assert torch.isfinite(got).all() and err < tol
+    assert torch.equal(ops.range_values(out_amax).cpu(), got.abs().amax(dim=(1, 2)).cpu())
+
+
 SA_CASES = [(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128), (128, 128, 256, 64), (128, 196, 256, 128)]
 
 
-@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("bf16x3", 4e-6), ("f16x2", 8e-6), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("f32", 2e-6), ("bf16x3", 4e-6), ("f16x2", 8e-6), ("bf16", 2e-2), ("f16", 3e-3)])
 @pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
 def test_sa_mlp_max(C1, C2, C3, K, precision, tol):
     _need_gpu()
@@ -333,10 +376,11 @@ def test_sa_mlp_max(C1, C2, C3, K, precision, tol):
     assert err < tol
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x2", 8e-6), ("f16", 3e-3)])
 @pytest.mark.parametrize("mag", [1.0, 1e-3, 3e4])
 @pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
-def test_sa_mlp_max_f16x2_layer1_from_raw_features(C1, C2, C3, K, mag):
-    """F16X2: layer 1 on the matrix pipe straight from the raw feature rows, one power of two PER NEIGHBOUR (ev2h_sa_desc.feat), with
+def test_sa_mlp_max_f16x2_layer1_from_raw_features(C1, C2, C3, K, mag, precision, tol):
+    """F16X2 (and F16 [r6]: the same layer 1, one fp16 plane in layers 2-3): layer 1 on the matrix pipe straight from the raw feature rows, one power of two PER NEIGHBOUR (ev2h_sa_desc.feat), with
     the range handling on: features of magnitude `mag` next to O(1) coordinates, and one neighbour per window whose feature is 1e6 x
     larger (a hot pixel) -- fp32-class against the float64 restatement of pointnet2_utils.py:244-257."""
     _need_gpu()
@@ -368,10 +412,10 @@ def test_sa_mlp_max_f16x2_layer1_from_raw_features(C1, C2, C3, K, mag):
     amax.view(torch.float32).copy_(feat.abs().amax((1, 2)))
     dmax = float(dxyz.abs().max()) * 1.0001
     got = ops.sa_mlp_max(None, ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2p.cuda(), b2p.cuda(), W3p.cuda(),
-                         b3.cuda(), C2, "f16x2", feat=feat.cuda(), W1f=W1f.cuda(), b1=b1.cuda(), feat_amax=amax, dmax=dmax)
+                         b3.cuda(), C2, precision, feat=feat.cuda(), W1f=W1f.cuda(), b1=b1.cuda(), feat_amax=amax, dmax=dmax)
     err = rel(got, ref)
-    print(f"sa<{C1},{C2},{C3}> f16x2 layer 1 from raw features (|f| ~ {mag:g}, hot pixel x1e6): rel err {err:.2e}")
-    assert torch.isfinite(got).all() and err < 8e-6
+    print(f"sa<{C1},{C2},{C3}> {precision} layer 1 from raw features (|f| ~ {mag:g}, hot pixel x1e6): rel err {err:.2e}")
+    assert torch.isfinite(got).all() and err < tol
 
 
 @pytest.mark.parametrize("C1,C2,C3,K", SA_CASES)
@@ -454,7 +498,7 @@ def test_sa_mlp_max_bf16x3_layer1_from_raw_features(C1, C2, C3, K, mag):
     assert torch.isfinite(got).all() and e_ref < 8e-6 and e_tab < 8e-6
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "bf16"])
+@pytest.mark.parametrize("precision", ["f16x2", "bf16x3", "bf16", "f16"])
 @pytest.mark.parametrize("C1,C2,C3,K", [(64, 96, 128, 128), (128, 196, 256, 128), (128, 128, 256, 64)])
 def test_sa_mlp_max_skips_padding_strips(C1, C2, C3, K, precision):
     """query_ball_point pads the slots past a group's neighbour count with slot 0 (pointnet2_utils.py:104-106); given the

@@ -51,14 +51,40 @@ def test_hidden_activation_magnitude_does_not_matter(alpha, precision):
     check_against(out, net, ref, trace, B, N)
 
 
+@pytest.mark.parametrize("alpha", [1e-4, 1e3, 1e6])
+def test_f16_mode_shares_the_range_machinery(alpha):
+    """[r6] The one-plane fp16 mode reads the same range records: hidden activations 1e-4 ... 1e6 x O(1) (far outside fp16's range
+    unscaled) leave its error where it is for O(1) activations -- the mode's own rounding (2^-11 per operand), nothing from range."""
+    _need_gpu()
+    C, N, B, seed = 4, 1024, 2, 11
+    res = {}
+    for a in (1.0, alpha):
+        sd = sc.rescale_hidden(synth.synth_state_dict(C, seed), a)
+        net, assets = _net(C, sd, seed, "f16")
+        xyz = synth.synth_cloud("E", B, C, N, seed)
+        inits = synth.fps_inits(B, N, seed)
+        ref, _trace = run_oracle(sd, assets, xyz, inits)
+        net.net.fps_init = inits
+        with torch.no_grad():
+            out = net(xyz.cuda())
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(out[s_][k]).all() for s_ in ("left", "right") for k in ("vertices", "j3d")) and torch.isfinite(out["class_logits"]).all()
+        agree = float((out["class_logits"].argmax(1).cpu() == ref["class_logits"].argmax(1)).float().mean())
+        res[a] = (rel(out["class_logits"], ref["class_logits"]), max(rel(out[s_]["j3d"], ref[s_]["j3d"]) for s_ in ("left", "right")), agree)
+    print(f"f16, hidden activations x {alpha:g}: logits rel {res[alpha][0]:.2e} (x 1: {res[1.0][0]:.2e}), joints rel {res[alpha][1]:.2e} ({res[1.0][1]:.2e}), argmax {res[alpha][2]:.4f}")
+    assert res[alpha][0] < 3e-3 and res[alpha][1] < 3e-3 and res[alpha][2] > 0.995
+    assert res[alpha][0] < 4 * res[1.0][0] + 1e-4 and res[alpha][1] < 4 * res[1.0][1] + 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f16x2", "f16"])
 @pytest.mark.parametrize("alpha", [1e-4, 1.0, 1e6])
-def test_windows_of_one_batch_are_scaled_independently(alpha):
+def test_windows_of_one_batch_are_scaled_independently(alpha, precision):
     """A batch that mixes a normal window with one whose INPUT features are 1e4 times larger: every window must come out
     exactly as when it is run alone (the scales are per window, so sharding a batch never changes a result)."""
     _need_gpu()
     C, N, seed = 5, 512, 12
     sd = sc.rescale_hidden(synth.synth_state_dict(C, seed), alpha)
-    net, assets = _net(C, sd, seed, "f16x2")
+    net, assets = _net(C, sd, seed, precision)
     xyz = synth.synth_cloud("E", 3, C, N, seed)
     xyz[1, 3:] *= 1e4                                   # event counts of window 1: far larger than its neighbours'
     inits = synth.fps_inits(3, N, seed)
@@ -67,7 +93,8 @@ def test_windows_of_one_batch_are_scaled_independently(alpha):
         net.net.fps_init = inits
         full = net(xyz.cuda())
         torch.cuda.synchronize()
-        check_against(full, net, ref, trace, 3, N)           # (reads the debug buffers of THIS forward)
+        if precision == "f16x2":
+            check_against(full, net, ref, trace, 3, N)       # (reads the debug buffers of THIS forward)
         full = {"class_logits": full["class_logits"].clone(),
                 **{s_: {k: v.clone() for k, v in full[s_].items() if torch.is_tensor(v)} for s_ in ("left", "right")}}
         outs = []

@@ -35,7 +35,7 @@ def test_struct_layouts_and_abi_version(built):
     built.ev2h_struct_sizes(sizes)
     mine = [C.sizeof(t) for t in (_lib.GemmDesc, _lib.SaDesc, _lib.SaModule, _lib.Weights, _lib.ManoConsts, _lib.Outputs, _lib.FpDesc, _lib.TensorDesc)]
     assert list(sizes) == mine
-    assert built.ev2h_abi_version() == 7 == _lib.ABI_VERSION
+    assert built.ev2h_abi_version() == 8 == _lib.ABI_VERSION
 
 
 def test_workspace_size_grows_linearly(built):
@@ -413,3 +413,32 @@ def test_default_arithmetic_mode_is_auto(monkeypatch):
     monkeypatch.setenv("EV2H_PRECISION", "f32")
     assert TEHNetWrapper("cpu", mano_assets=assets).net.precision == "f32"
     assert TEHNetWrapper("cpu", mano_assets=assets).net.AUTO_TOLERANCE == 5e-5
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, built):
+    """[r6] The binary is git-ignored but travels (gpurun snapshot, copies between machines): ev2hands_amd/build.py stamps the
+    sha256 of csrc/ + include/ into it and _lib.lib() recomputes the hash of the sources next to it.  A copy of the package whose
+    sources differ by ONE byte from what its .so was built from must refuse to load (and say how to fix it); the same copy with
+    EV2H_LIB_PATH naming the binary explicitly loads (the documented opt-out); needs_build() is the same comparison, so
+    __graft_entry__.build() either matches provably or rebuilds."""
+    import shutil
+    import subprocess
+    import sys
+    from ev2hands_amd import build
+    assert build.built_hash() == build.source_hash() and not build.needs_build()
+    assert built.ev2h_source_hash().decode() == build.source_hash()
+    root = tmp_path / "copy"
+    shutil.copytree(os.path.join(ROOT, "ev2hands_amd"), root / "ev2hands_amd", ignore=shutil.ignore_patterns(".obj", "__pycache__"))
+    shutil.copytree(os.path.join(ROOT, "include"), root / "include")
+    probe = ("import sys; sys.path.insert(0, %r)\nfrom ev2hands_amd import _lib, build\nprint('needs_build', build.needs_build())\n"
+             "_lib.lib(); print('loaded')\n" % str(root))
+    env = {k: v for k, v in os.environ.items() if k != "EV2H_LIB_PATH"}
+    ok = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert ok.returncode == 0 and "needs_build False" in ok.stdout and "loaded" in ok.stdout, ok.stdout + ok.stderr
+    with open(root / "ev2hands_amd" / "csrc" / "mano.hip", "a") as f:
+        f.write("\n")                                              # one byte
+    bad = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert bad.returncode != 0 and "needs_build True" in bad.stdout and "built from other sources" in bad.stderr and "loaded" not in bad.stdout, bad.stdout + bad.stderr
+    env["EV2H_LIB_PATH"] = str(root / "ev2hands_amd" / "libev2hands_hip.so")
+    opt = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert opt.returncode == 0 and "loaded" in opt.stdout, opt.stdout + opt.stderr

@@ -61,7 +61,7 @@ def _compare(sd, C_in, precision, equalize):
     assert got.struct.flags == (_lib.W_EQUALIZED if equalize else _lib.W_UNEQUALIZED_OK)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16x2", "bf16x3", "f16"])
 @pytest.mark.parametrize("C_in,seed", [(4, 0), (5, 3)])
 def test_c_packer_equals_the_numpy_restatement(precision, C_in, seed):
     _compare(synth.synth_state_dict(C_in, seed), C_in, precision, True)
@@ -92,6 +92,34 @@ def test_c_packer_on_stress_checkpoints(kind):
         return
     _compare(sd, 4, "f16x2", True)
     _compare(sd, 4, "bf16x3", True)
+    if kind in ("channels8", "hidden1e-4"):
+        _compare(sd, 4, "f16", True)
+
+
+def test_f16_family_mask_packs_each_family_in_its_own_plane_mode():
+    """ev2h_pack_weights(EV2H_PREC_F16, EV2H_PACK_F16_FAMILIES(mask)): the families inside the mask get ONE fp16 plane (the images
+    the all-families pack holds), the others the two-plane images the F16X2 pack holds -- byte for byte -- and the fp32 arrays
+    are the same in all three."""
+    sd = synth.synth_state_dict(4, 5)
+    full = pack.PackedWeights(sd, "cpu", 4, "f16")
+    two = pack.PackedWeights(sd, "cpu", 4, "f16x2")
+    assert full.struct.f16_families == _lib.FAM_ALL and two.struct.f16_families == 0
+    fam_of = lambda name: (_lib.FAM_SA if name.startswith(("sa1.", "sa2.")) or ".sa1." in name else
+                           _lib.FAM_ROWS if name.startswith(("fp1m.", "clsm.")) else
+                           _lib.FAM_QCONV if name.startswith("qconv0.") else _lib.FAM_DENSE)      # noqa: E731
+    for mask in (_lib.FAM_SA, _lib.FAM_ROWS | _lib.FAM_QCONV, _lib.FAM_DENSE):
+        mixed = pack.PackedWeights(sd, "cpu", 4, "f16", f16_families=mask)
+        assert mixed.struct.f16_families == mask and mixed.struct.precision == _lib.PREC["f16"]
+        assert sorted(mixed.tensors) == sorted(full.tensors) == sorted(two.tensors)
+        nimg = 0
+        for name, t in mixed.tensors.items():
+            if t.dtype == torch.uint8:                   # a plane image
+                src = full if fam_of(name) & mask else two
+                assert torch.equal(t, src.tensors[name]), (mask, name)
+                nimg += 1
+            else:
+                assert torch.equal(t, full.tensors[name]) and torch.equal(t, two.tensors[name]), name
+        assert nimg > 20
 
 
 def test_strict_schema_errors():

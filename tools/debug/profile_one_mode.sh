@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out; TAG=r5
 PY=$(python3 -c "import sys; print(sys.executable)")
-BENCH="bench.py --steps 7 --warmup 3 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
-SMALL="bench.py --steps 2 --warmup 1 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
+BENCH="bench.py --steps 7 --warmup 3 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-sustained --no-host-io"
+SMALL="bench.py --steps 2 --warmup 1 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-sustained --no-host-io"
 prec=${1:-bf16x3}
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt_$prec -o bench -- $PY $BENCH --precision $prec > $O/${TAG}_ktlog_$prec.txt 2>&1
 python tools/rocpd_summary.py $(ls $O/${TAG}_kt_$prec/*/*.db $O/${TAG}_kt_$prec/*.db 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats_$prec.txt 2>&1

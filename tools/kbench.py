@@ -54,7 +54,7 @@ def bench_sa(B=256, precision="f32"):
             dd.out, dd.ldo = out.data_ptr(), C3
             dd.B, dd.Npts, dd.S, dd.K, dd.C1, dd.C2, dd.C3, dd.precision = B, Npts, S, K, C1, C2, C3, _lib.PREC[precision]
             dd.w2_unscale, dd.w3_unscale = u2, u3
-            if os.environ.get("KBENCH_FEAT") and precision == "bf16":      # layer 1 from raw feature rows (enc.sa1, the regressors' sa1)
+            if os.environ.get("KBENCH_FEAT"):      # layer 1 from raw feature rows (enc.sa1, the regressors' sa1)
                 feat = torch.randn(B, Npts, 8, device=d)
                 W1f, b1 = torch.randn(C1, 4, device=d) * 0.5, torch.randn(C1, device=d)
                 dd.feat, dd.ldf, dd.W1f, dd.ldw1f, dd.b1, dd.nfeat = feat.data_ptr(), 8, W1f.data_ptr(), 4, b1.data_ptr(), 4

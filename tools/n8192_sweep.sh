@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 PY=$(python3 -c "import sys; print(sys.executable)")
-COMMON="--points 8192 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
+COMMON="--points 8192 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-sustained --no-host-io"
 {
 echo "# N = 8192 batch sweep (windows per GPU per step), f16x2, E clouds: python bench.py --points 8192 --batch B"
 for b in 1 4 16 32 64 128; do

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 PY=$(python3 -c "import sys; print(sys.executable)")   # the interpreter itself follows `--`; a symlink is not an exec hop and resolving it would leave a virtualenv
-ARGS="--points 8192 --batch 128 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io"
+ARGS="--points 8192 --batch 128 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-second-site --no-host-io --no-sustained"
 export EV2H_TWO_STREAMS=0
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_kt8k -o bench -- $PY bench.py --steps 7 --warmup 3 $ARGS > $O/${TAG}_ktlog_n8192.txt 2>&1
 python tools/rocpd_summary.py $(ls $O/${TAG}_kt8k/*/*.db $O/${TAG}_kt8k/*.db 2>/dev/null | head -1) > $O/${TAG}_bench_kernel_stats_n8192_f16x2_single_stream.txt 2>&1

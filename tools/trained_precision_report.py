@@ -2,7 +2,9 @@
 batch the CPU reference would need minutes for: every mode against the exact-fp32 MFMA mode of this library (which the GPU tests
 hold to the reference-run fixtures), plus what the f16x2 guard reports -- TEHNet.verify_precision (f16x2 vs bf16x3 on the batch),
 the range report of the materialised operands and the packed-weight spread.
-    python tools/trained_precision_report.py [B]      ->  profiles/r5_trained_precision_report.txt"""
+    python tools/trained_precision_report.py [B]      ->  profiles/r6_trained_precision_report.txt
+[r6] with "f16" (one fp16 plane under f16x2's range records) next to "bf16", and the root-relative MPJPE of
+evaluate_ev2hands_r.py:43-54 (each hand's joints minus its root joint) next to the absolute one."""
 import os
 import sys
 
@@ -31,7 +33,7 @@ for C, kind, seed in ((4, "E", 51), (4, "U", 52), (5, "E", 53)):
     xyz = synth.synth_cloud(kind, B, C, N, seed).cuda()
     inits = synth.fps_inits(B, N, seed)
     outs = {}
-    for prec in ("f32", "bf16x3", "f16x2", "bf16"):
+    for prec in ("f32", "bf16x3", "f16x2", "f16", "bf16"):
         net = TEHNetWrapper("cuda:0", mano_assets=assets, precision=prec)
         net.load_state_dict(sd, strict=True)
         net.eval()
@@ -51,12 +53,18 @@ for C, kind, seed in ((4, "E", 51), (4, "U", 52), (5, "E", 53)):
     scale = float(r["logits"].abs().max())
     print(f"## trained checkpoint C={C}, {kind}-clouds, B={B}, N={N}: logit scale {scale:.3f}, top-2 margin < 1e-4 scale at "
           f"{float((margin < 1e-4 * scale).float().mean()) * 100:.3f} % of the points, class histogram {torch.bincount(r['logits'].argmax(1).flatten(), minlength=4).tolist()}")
-    for prec in ("bf16x3", "f16x2", "bf16"):
+    def rootrel(j):          # [B, 42, 3]: left joints 0..20, right 21..41, each minus its own root (evaluate_ev2hands_r.py:43-54)
+        j = j.double().view(j.shape[0], 2, 21, 3)
+        return (j - j[:, :, :1]).view(j.shape[0], 42, 3)
+    for prec in ("bf16x3", "f16x2", "f16", "bf16"):
         o = outs[prec]
         agree = (o["logits"].argmax(1) == r["logits"].argmax(1))
         mp = float((o["j3d"] - r["j3d"]).double().norm(dim=-1).mean()) * 1e3
+        mpr = float((rootrel(o["j3d"]) - rootrel(r["j3d"])).norm(dim=-1).mean()) * 1e3
+        mpw = float((o["j3d"] - r["j3d"]).double().norm(dim=-1).mean(1).max()) * 1e3
         print(f"  {prec:7s} vs f32: logits {rel(o['logits'], r['logits']):.2e}  params {rel(o['params'], r['params']):.2e}  vertices {rel(o['verts'], r['verts']):.2e}  "
-              f"joints {rel(o['j3d'], r['j3d']):.2e}  MPJPE {mp:.4f} mm  argmax differs at {int((~agree).sum())} of {agree.numel()} points")
+              f"joints {rel(o['j3d'], r['j3d']):.2e}  MPJPE {mp:.4f} mm (worst window {mpw:.4f})  root-relative MPJPE {mpr:.4f} mm  "
+              f"argmax agreement {float(agree.float().mean()) * 100:.4f} % ({int((~agree).sum())} of {agree.numel()} points differ)")
     worst = sorted(rep["range"].items(), key=lambda kv: -kv[1]["worst_fraction"])[:4]
     print(f"  verify_precision (f16x2 vs bf16x3 on this batch): max_rel {rep['max_rel']:.2e}, argmax agreement {rep['argmax_agreement']:.6f}, ok(<= {net.net.AUTO_TOLERANCE:g}) = {rep['ok']}")
     print("  range report, operands with the largest share of values more than 2^17 below their window's maximum: "
