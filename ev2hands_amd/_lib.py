@@ -51,7 +51,7 @@ class SaBranch(C.Structure):
     _fields_ = [("W1x", vp), ("W2", vp), ("b2", vp), ("W3", vp), ("b3", vp),
                 ("C1", ci), ("C2", ci), ("C3", ci), ("K", ci), ("radius", C.c_double), ("W2s", vp), ("W3s", vp),
                 ("w2_unscale", C.c_float), ("w3_unscale", C.c_float), ("w1x_norm", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
-                ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float)]
+                ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float), ("w3_norm", C.c_float), ("b3_max", C.c_float)]
 
 
 class SaModule(C.Structure):

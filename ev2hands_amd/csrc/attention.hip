@@ -171,11 +171,12 @@ __global__ __launch_bounds__(1024) void attn_simfold_kernel(const float* __restr
 // one wave per point: lanes hold 4 channels each of the 256-wide value row, both hands' sim in registers
 constexpr int CTX_PTS_PER_WAVE = 32;
 // VBF16: the value rows are bf16 (the BF16 mode stores l0 that way, forward.hip); ldv counts values either way
-template <bool VBF16>
+// VBF16: 0 = float32 value rows, 1 = bf16 rows (BF16 mode), 2 [r6] = fp16 rows stored times the per-window power of two vscale[b] (F16 mode)
+template <int VBF16>
 __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restrict__ sim, const float* __restrict__ value,
                                                            int ldv, int N, size_t rows_total, float* __restrict__ hf8,
                                                            unsigned* __restrict__ amax, int amax_hand_stride,
-                                                           const float* __restrict__ value_unscale) {
+                                                           const float* __restrict__ value_unscale, const float* __restrict__ vscale = nullptr) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float4 w[2][4];
@@ -187,6 +188,10 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
         for (int c = 0; c < 4; ++c) {
             float4 t = *reinterpret_cast<const float4*>(sim + (((size_t)b * 2 + h) * 4 + c) * ATT_D + lane * 4);
             t.x *= vu.x; t.y *= vu.y; t.z *= vu.z; t.w *= vu.w;
+            if constexpr (VBF16 == 2) {                   // the rows' power of two is undone on the weights, once per workgroup (exact)
+                const float iv = 1.f / vscale[b];
+                t.x *= iv; t.y *= iv; t.z *= iv; t.w *= iv;
+            }
             w[h][c] = t;
         }
     const int n0 = (blockIdx.x * 4 + wave) * CTX_PTS_PER_WAVE;
@@ -194,9 +199,14 @@ __global__ __launch_bounds__(256) void attn_context_kernel(const float* __restri
     for (int n = n0; n < n0 + CTX_PTS_PER_WAVE && n < N; ++n) {
         const size_t row = (size_t)b * N + n;
         float4 v;
-        if constexpr (VBF16) {
+        if constexpr (VBF16 == 1) {
             const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(value) + row * ldv + lane * 4);
             v = make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16), __uint_as_float(h.y & 0xffff0000u));
+        } else if constexpr (VBF16 == 2) {
+            typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+            const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(value) + row * ldv + lane * 4);
+            const h16x2 a = __builtin_bit_cast(h16x2, h.x), b_ = __builtin_bit_cast(h16x2, h.y);
+            v = make_float4((float)a[0], (float)a[1], (float)b_[0], (float)b_[1]);
         } else {
             v = *reinterpret_cast<const float4*>(value + row * ldv + lane * 4);
         }
@@ -283,7 +293,7 @@ extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ld
                                  int amax_hand_stride, const float* value_unscale, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
     dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
-    attn_context_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride, value_unscale);
+    attn_context_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(sim, value_pm, ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride, value_unscale);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }
@@ -292,7 +302,19 @@ extern "C" int ev2h_attn_context(const float* sim, const float* value_pm, int ld
 int ev2h_attn_context_bf16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, const float* value_unscale, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(sim && value_pm && hf8 && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
     dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
-    attn_context_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(sim, reinterpret_cast<const float*>(value_pm), ldv, N, (size_t)B * N, hf8, nullptr, 0, value_unscale);
+    attn_context_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(sim, reinterpret_cast<const float*>(value_pm), ldv, N, (size_t)B * N, hf8, nullptr, 0, value_unscale);
+    EV2H_CHECK_LAUNCH();
+    return EV2H_OK;
+}
+
+// internal (forward.hip, F16 mode) [r6]: fp16 value rows stored times the per-window power of two vscale[b]; with the range records of
+// the two hands' context features (the F16 regressors scale by them)
+int ev2h_attn_context_f16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax, int amax_hand_stride,
+                              const float* value_unscale, const float* vscale, ev2h_stream_t stream) {
+    EV2H_CHECK_ARG(sim && value_pm && hf8 && vscale && B > 0 && N > 0 && ldv >= ATT_D && (ldv % 4) == 0);
+    dim3 grid(ceil_div(N, 4 * CTX_PTS_PER_WAVE), B);
+    attn_context_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(sim, reinterpret_cast<const float*>(value_pm), ldv, N, (size_t)B * N, hf8, hf_amax, amax_hand_stride,
+                                                                 value_unscale, vscale);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;
 }

@@ -205,8 +205,10 @@ extern "C" int ev2h_shader_clock_probe(ev2h_stream_t stream, int spin_us, unsign
 // ---------------------------------------------------------------------------------------- small kernels
 // internal entry points of other translation units (not part of the C ABI)
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d);
-int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream);
-int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream);
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream, const float* x_scale = nullptr);
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream, float* row16_scale = nullptr, float w3_norm = 0.f, float b3_max = 0.f);
+int ev2h_attn_context_f16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, uint32_t* hf_amax, int amax_hand_stride,
+                              const float* value_unscale, const float* vscale, ev2h_stream_t stream);
 int ev2h_attn_context_bf16rows(const float* sim, const void* value_pm, int ldv, int B, int N, float* hf8, const float* value_unscale, ev2h_stream_t stream);
 int ev2h_attn_simfold_partials(const float* zpart, int rows_per_partial, const float* logits_pm, int B, int N, const float* w4t_left,
                                const float* w4t_right, const float* b4_left, const float* b4_right, float* sim, ev2h_stream_t stream);
@@ -312,7 +314,7 @@ static void build_layout(Layout& L, int B, int N) {
         L.add(kHandNames[h][9], b * 1024);
     }
     L.add("ranges", (size_t)R_COUNT * b);       // F16X2 range records (uint32 [R_COUNT][B]) ...
-    L.add("p1scale", 5 * b);                    // ... and the storage scales of the five layer-1 tables (float [5][B])
+    L.add("p1scale", 6 * b);                    // ... and the storage scales of the five layer-1 tables (float [5][B]) + [5]: of l0 when it is stored as fp16 (F16)
 }
 
 struct Ws {
@@ -451,6 +453,8 @@ static int sa_module(int precision, const char* tag, const ev2h_sa_module& m, co
 // records: the consumer takes their maximum -- a concatenated input).  Not listed: operands that never reach memory (the hidden
 // layers inside the fused set-abstraction / row-chain kernels, whose scales come from bounds): TEHNet.verify_precision compares
 // whole forwards for those.
+static thread_local int g_last_l0_bf16 = 0;      // how the calling thread's last ev2h_forward stored l0: 0 float32, 1 bf16 (BF16), 2 fp16 x p1scale[5][b] (F16)
+
 struct SpreadEntry { const char* name; const char* buf; int rows; int ld; int col0; int ncols; int rec; int rec2; size_t hand_off; };
 
 static int spread_entries(int N, SpreadEntry* e) {      // rows == 0: N rows per window
@@ -482,9 +486,10 @@ constexpr int EV2H_MAX_SPREAD = 32;
 namespace {
 // counts[b] = {non-zero values, values with 0 < |v| s < 2^-3 (low fp16 plane subnormal: fewer than 22 bits survive the split),
 // values with 0 < |v| s < 2^-14 (high plane subnormal too: fewer than 11 bits)}, s = the consumer's power-of-two scale
+// half_elems: the buffer holds fp16 values (F16 mode's l0: stored times a power of two, and so is its record -- the ratios are the same)
 __global__ __launch_bounds__(256) void spread_count_kernel(const float* __restrict__ buf, size_t window_stride, int rows, int ld, int col0, int ncols,
                                                            const unsigned* __restrict__ rec, const unsigned* __restrict__ rec2,
-                                                           unsigned* __restrict__ counts) {
+                                                           unsigned* __restrict__ counts, int half_elems) {
     const int b = blockIdx.y;
     unsigned a = rec[b];
     if (rec2) a = max(a, rec2[b]);
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(256) void spread_count_kernel(const float* __restri
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t r = i / ncols;
         const int c = (int)(i - r * ncols);
-        const float v = fabsf(base[r * ld + col0 + c]) * s;
+        const float v = fabsf(half_elems ? (float)reinterpret_cast<const _Float16*>(buf)[(size_t)b * window_stride + r * ld + col0 + c] : base[r * ld + col0 + c]) * s;
         nz += v > 0.f;
         lo += v > 0.f && v < 0.125f;
         hi += v > 0.f && v < 6.103515625e-05f;
@@ -534,7 +539,8 @@ extern "C" int ev2h_range_report(void* workspace, int B, int N, uint32_t* counts
         const size_t per_window = (size_t)rows * e[i].ld;
         const int gx = (int)std::min<size_t>(64, ((size_t)rows * e[i].ncols + 4095) / 4096);
         spread_count_kernel<<<dim3(std::max(gx, 1), B), 256, 0, (hipStream_t)st>>>(p, per_window, rows, e[i].ld, e[i].col0, e[i].ncols, ws.r(e[i].rec),
-                                                                                  e[i].rec2 >= 0 ? ws.r(e[i].rec2) : nullptr, counts + (size_t)i * B * 3);
+                                                                                  e[i].rec2 >= 0 ? ws.r(e[i].rec2) : nullptr, counts + (size_t)i * B * 3,
+                                                                                  (!strcmp(e[i].buf, "l0") && g_last_l0_bf16 == 2) ? 1 : 0);
         EV2H_CHECK_LAUNCH();
     }
     return EV2H_OK;
@@ -547,11 +553,9 @@ extern "C" size_t ev2h_workspace_bytes(int B, int N) {
     return L.total;
 }
 
-static thread_local int g_last_l0_bf16 = 0;      // the calling thread's last ev2h_forward stored l0 as bf16 (BF16 mode, fused forms)
-
 extern "C" const void* ev2h_workspace_buffer_ex(void* workspace, int B, int N, const char* name, size_t* count, int* elem_type) {
     const void* p = ev2h_workspace_buffer(workspace, B, N, name, count);
-    if (elem_type) *elem_type = (p && !strcmp(name, "l0") && g_last_l0_bf16) ? 1 : 0;
+    if (elem_type) *elem_type = (p && !strcmp(name, "l0")) ? g_last_l0_bf16 : 0;      // 1 = bf16, 2 = fp16 times p1scale[5][b]
     return p;
 }
 
@@ -702,7 +706,12 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     }
     const bool zsum_ok = !unfused_zsum && prec != EV2H_PREC_F32 && w->qconv0.Ws && ev2h_gemm_bf16_zsum_supported(&qd);
     const bool l0_bf16 = prec == EV2H_PREC_BF16 && fp1_fused && cls_fused && zsum_ok && !l0_f32;
-    g_last_l0_bf16 = l0_bf16 ? 1 : 0;                      // (ev2h_workspace_buffer_ex tells a debugger what "l0" holds)
+    // [r6] F16: the same tensor as fp16 times a per-window power of two (ws.p1scale(5)): the fp1 chain chooses it from the bound of its own
+    // output, the three readers take the stored values as their operand plane (ev2h_fp_mlp_ex, ev2h_gemm_bf16_zsum, ev2h_attn_context_f16rows).
+    // Needs the row chains and the query convolution to run one-plane fp16 (ev2h_weights.f16_families) in their fused forms.
+    const bool l0_f16 = prec == EV2H_PREC_F16 && prec_rows == EV2H_PREC_F16 && prec_q == EV2H_PREC_F16 && ws.ranges_on && fp1_fused && cls_fused && zsum_ok && !l0_f32;
+    const bool l0_16 = l0_bf16 || l0_f16;
+    g_last_l0_bf16 = l0_bf16 ? 1 : (l0_f16 ? 2 : 0);       // (ev2h_workspace_buffer_ex tells a debugger what "l0" holds)
     if (fp1_fused) {
         // 16-bit modes: the first layer commutes with the interpolation -- a 512-row table per window instead of an N-row GEMM --
         // and the blend of three table rows, layers 2-3 and the ReLUs run in one kernel (ev2h_fp_mlp): the interpolated rows and
@@ -719,7 +728,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
             d.t_scale = ws.p1scale(4); d.t_amax = ws.r(R_FP1T); d.w2_norm = m.br[0].w2_norm; d.b2_max = m.br[0].b2_max; d.out_amax = ws.r(R_L0);
         }
         prof_begin("fp1", st);
-        RUN(ev2h_fp_mlp_ex(&d, 0, l0_bf16, st));
+        RUN(ev2h_fp_mlp_ex(&d, 0, l0_16, st, l0_f16 ? ws.p1scale(5) : nullptr, m.br[0].w3_norm, m.br[0].b3_max));
         prof_end("fp1", st);
     } else {
         RUN(ev2h_three_nn_interp(ws.f("pts4"), ws.f("ctr1"), B, N, 512, ws.f("l1new"), 128, 128, ws.f("fp1in"), 128,
@@ -744,7 +753,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         d.out = ws.f("logits_pm"); d.ldo = 4; d.out_cols = 4; d.no_relu_out = 1; d.out_cm = out->class_logits; d.out_cm_stride = out->logits_stride;
         d.B = B; d.N = N; d.C1 = c.C1; d.C2 = c.C2; d.C3 = c.C3; d.precision = prec_rows;
         if (ws.ranges_on) { d.t_amax = ws.r(R_L0); d.w2_norm = c.w2_norm; d.b2_max = c.b2_max; }
-        RUN(ev2h_fp_mlp_ex(&d, l0_bf16, 0, sx));
+        RUN(ev2h_fp_mlp_ex(&d, l0_16, 0, sx, l0_f16 ? ws.p1scale(5) : nullptr));
     } else {
         RUN(dense(w->cls0, ws.f("l0"), 256, R, ws.f("clsh"), 256, 1, sx, rg(R_L0, N, R_CLSH, N)));
         RUN(dense(w->cls4, ws.f("clsh"), 256, R, ws.f("logits_pm"), 4, 0, sx, rg(R_CLSH, N)));
@@ -762,7 +771,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         // per step, and a genuine error of the fused launch is returned, never turned into the two-pass schedule
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[7], 0));          // logits ready
         prof_begin("qconv0", st);
-        RUN(ev2h_gemm_bf16_zsum(&qd, ws.f("logits_pm"), ws.f("zpart"), l0_bf16, st));
+        RUN(ev2h_gemm_bf16_zsum(&qd, ws.f("logits_pm"), ws.f("zpart"), l0_16, st, l0_f16 ? ws.p1scale(5) : nullptr));
         prof_end("qconv0", st);
         zsum_fused = true;
     }
@@ -783,6 +792,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
                                  ws.f("zpart"), ws.f("sim"), st));
     }
     if (l0_bf16) RUN(ev2h_attn_context_bf16rows(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), w->l0_unscale, st));
+    else if (l0_f16) RUN(ev2h_attn_context_f16rows(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, w->l0_unscale, ws.p1scale(5), st));
     else RUN(ev2h_attn_context(ws.f("sim"), ws.f("l0"), 256, B, N, ws.f("hf8"), ws.r(R_HF), B, w->l0_unscale, st));
     // ---- MANO regressors (TEHNet.py:194-195, 68-112): left on the caller's stream, right on the side stream
     if (fork) {

@@ -38,7 +38,8 @@ struct GemmBP {
     // TAP3 occupancy kernel only: the attention's key-weighted column sums (attention.hip: Z[c][t][i]) formed in the epilogue instead of
     // storing Y -- zs_key = logits, point-major [M][4]; zs_out = chunk partials [M / 128][12][N] (see zsum_epilogue)
     const float4* zs_key; float* zs_out;
-    int x_bf16;             // TAP3 kernel, NS = 1 only (internal): X holds bf16 values (ldx counts values) -- the rows ARE the operand plane
+    int x_bf16;             // TAP3 kernel, NS = 1 / NS = 4 only (internal): X holds bf16 / fp16 values (ldx counts values) -- the rows ARE the operand plane
+    const float* x_scale;   // NS = 4 with x_bf16 [r6]: the power of two each group's fp16 rows were stored with (float [groups]); replaces x_amax
 };
 
 template <int NS>
@@ -53,6 +54,10 @@ struct GBCfg {
 template <int NS>
 __device__ __forceinline__ float x_row_scale(const GemmBP& p, long m) {
     if constexpr (!planes_f16(NS)) return 1.f;
+    if (p.x_scale) {                         // fp16 rows stored scaled: that power of two IS the operand's scale
+        const long mm = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
+        return p.x_scale[mm / p.x_group_rows];
+    }
     if (!p.x_amax) return 1.f;
     const long mm = m < 0 ? 0 : (m < p.M ? m : p.M - 1);
     const long g = mm / p.x_group_rows;
@@ -487,7 +492,7 @@ __device__ __forceinline__ void zsum_epilogue(const GemmBP& p, f32x16 (&acc)[2][
         tj[j] = (p.post_shift && okc) ? p.post_shift[col] : 0.f;
     }
     float cx = p.w_unscale;
-    if (planes_f16(NS) && p.x_amax) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
+    if (planes_f16(NS) && (p.x_amax || p.x_scale)) cx = p.w_unscale * pow2_inverse(x_row_scale<NS>(p, m0));
     float amf = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
         const int k = kc * GB_BK + lseg * 16;
         const int m = m0 + lrow;
         oka = m < p.M;
-        const bool xh = (NS == 1) && p.x_bf16;
+        const bool xh = (NS == 1 || NS == 4) && p.x_bf16;
         if (xh) load16h(reinterpret_cast<const unsigned short*>(p.X) + (oka ? (long)m : 0) * p.ldx + k, ra);
         else load16(p.X + (oka ? (long)m : 0) * p.ldx + k, true, ra);            // TAP3: Kc % 32 == 0
         if (tid < 4) {
@@ -677,8 +682,8 @@ __global__ __launch_bounds__(GO_THREADS, 3) void gemm_nt_bf16_occ_kernel(GemmBP 
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]) : : "memory");
     };
     auto swrite_row = [&](const f32x4 (&r)[4], bool ok, int ldsrow, float sc) {
-        if constexpr (NS == 1 && TAP3) {
-            if (p.x_bf16) {               // the loaded 32 bytes are the plane: two 16-byte pieces of this row's k half
+        if constexpr ((NS == 1 || NS == 4) && TAP3) {
+            if (p.x_bf16) {               // the loaded 32 bytes are the plane (F16: stored with the group's power of two): two 16-byte pieces of this row's k half
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     u32x4 v = __builtin_bit_cast(u32x4, r[hh]);
@@ -1007,9 +1012,9 @@ bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d) {
     return true;
 }
 
-int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream) {
+int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream, const float* x_scale) {
     EV2H_CHECK_ARG(d && key_pm && zpart && ev2h_gemm_bf16_zsum_supported(d));
-    EV2H_CHECK_ARG(!x_bf16 || d->precision == EV2H_PREC_BF16);
+    EV2H_CHECK_ARG(!x_bf16 || d->precision == EV2H_PREC_BF16 || (d->precision == EV2H_PREC_F16 && x_scale && d->x_group_rows > 0));
     GemmBP p{};
     p.X = d->X; p.ldx = d->ldx; p.W = d->W; p.ldw = d->ldw; p.Y = nullptr; p.ldy = 0;
     p.M = d->M; p.N = d->N; p.taps = 3; p.Kc = d->K; p.K = d->K * 3;
@@ -1022,6 +1027,7 @@ int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpa
     }
     p.zs_key = reinterpret_cast<const float4*>(key_pm); p.zs_out = zpart;
     p.x_bf16 = x_bf16;
+    if (x_bf16 && d->precision == EV2H_PREC_F16) { p.x_scale = x_scale; p.x_amax = p.x_amax2 = nullptr; p.x_group_rows = d->x_group_rows; }
     p.tiles_n = d->N / GO_BN;
     p.nblk = (d->M / GB_BM) * p.tiles_n;
 #ifdef EV2H_GEMM_ONE_BODY

@@ -657,6 +657,8 @@ struct Builder {
             }
             br.w2_norm = bound(max_row_l1(L1.W.data(), C2, C1, C1));
             br.b2_max = bound(max_abs(L1.b));
+            br.w3_norm = bound(max_row_l1(L2.W.data(), C3, C2, C2));
+            br.b3_max = bound(max_abs(L2.b));
             if (ns) chain_images(br, n, L1.W.data(), L2.W.data(), C1, C2, C3, EV2H_FAM_SA);
             r0 += C1;
         }
@@ -688,6 +690,8 @@ struct Builder {
         br.w1x_norm = 0.f;
         br.w2_norm = bound(max_row_l1(L1.W.data(), L1.O, L1.I, L1.I));
         br.b2_max = bound(max_abs(L1.b));
+        br.w3_norm = bound(max_row_l1(L2.W.data(), L2.O, L2.I, L2.I));
+        br.b3_max = bound(max_abs(L2.b));
         chain_images(br, n, L1.W.data(), L2.W.data(), L0.O, L1.O, L2.O, EV2H_FAM_ROWS);
         dev(&m.W1f, n + ".W1f", L0.W.data(), L0.O, L0.I);
         vec(&m.b1, n + ".b1", L0.b);
@@ -718,6 +722,8 @@ struct Builder {
         br.w1x_norm = 0.f;
         br.w2_norm = bound(max_row_l1(c0.W.data(), C2, C1, C1));
         br.b2_max = bound(max_abs(c0.b));
+        br.w3_norm = bound(max_row_l1(W4p.data(), 32, C2, C2));
+        br.b3_max = bound(max_abs(b4p));
         chain_images(br, "clsm", c0.W.data(), W4p.data(), C1, C2, 32, EV2H_FAM_ROWS);
     }
 

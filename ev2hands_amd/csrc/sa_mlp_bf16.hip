@@ -77,6 +77,11 @@ struct SaBP {
     // ldo still count VALUES) -- l0, the one N-row 256-wide tensor of the forward, is written once and read three times, and
     // every reader of the BF16 mode rounds it to bf16 before it multiplies anyway
     int t_bf16, out_bf16;
+    // F16 row chains only (internal, ev2h_fp_mlp_ex) [r6]: the same for the one-plane fp16 mode -- the rows are fp16 values TIMES a
+    // per-window power of two row16_scale[b] (float [B]).  The writer (out_bf16, fp1) chooses it from the rigorous bound of its own
+    // output (|W3|_1 bound(H2) + max|b3|: known before the first row is computed), stores it and records max |stored|; the reader
+    // (t_bf16, the segmentation head) takes the stored values as its operand plane as they are and the scale as its s1.
+    float* row16_scale; float w3_norm, b3_max;
 };
 
 // EV2H_SAB_TIMELINE build (EV2H_BUILD_DEFS=-DEV2H_SAB_TIMELINE python -m ev2hands_amd.build --force; tools/sa_timeline.py):
@@ -160,8 +165,20 @@ struct SaBCfg {
 // MODE = 1, 2 (streamed only): the row chains of ev2h_fp_mlp -- same tile walk, but the layer-3 tiles are written out row by row
 //              instead of maximised, and layer 1 is (1) the inverse-distance blend of three table rows (no relative xyz) or (2) the
 //              input row itself.
+// Waves per SIMD the register allocator must leave room for: 2 (256 registers) everywhere, except F16's resident feature-row kernels
+// whose LDS footprint lets TWO workgroups share a CU -- BF16's get under 128 registers by themselves (124), F16's 64-96-128 needs 138
+// and is held to 128 (32 bytes of scratch outside the MFMA loops): kbench 0.81 -> 0.73 ms (tools/kbench.py sab, KBENCH_FEAT=1).
+// EV2H_BUILD_DEFS=-DEV2H_F16_RES_ONE_WG: build without (A/B).
+template <int C1, int C2, int C3, int NS, bool RES, int MODE>
+constexpr int sab_min_waves() {
+#ifdef EV2H_F16_RES_ONE_WG
+    return 2;
+#else
+    return (NS == 4 && RES && MODE == 3 && 2 * SaBCfg<C1, C2, C3, NS>::RES_LDS_BYTES <= 160 * 1024) ? 4 : 2;
+#endif
+}
 template <int C1, int C2, int C3, int NS, bool RES, int MODE = 0>
-__global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p) {
+__global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MODE>())) void sa_mlp_max_bf16_kernel(SaBP p) {
     constexpr int WV = SAB_WAVES;
     // MODE = 3: the set abstraction with RAW FEATURE ROWS compiled in (L1M / L1F below; MODE 0 is then the table form only) -- see
     //              sab_split_forms above.
@@ -360,6 +377,7 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
     // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
     float s1 = 1.f, c2 = p.u2, c3 = p.u3;
+    float so = 1.f;                                             // F16 row chain with fp16 output rows: their per-window power of two
     float b1s_f = 1.f, b1s_x = 1.f, b1s_b = 1.f;               // F16 L1M: the B operand's factors s1 a1f, s1 a1x, s1 a1b (wave-uniform)
     const bool fform = fmode || (L1M && hasfeat);               // layer 1 reads raw feature rows (no table, no producer that chose s1)
     if constexpr (F16) {
@@ -372,7 +390,10 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             c3 = p.u3 * pow2_inverse(s2);
         } else if (!fform && p.p1_amax) {
             float a1 = __uint_as_float(p.p1_amax[b]);
-            if constexpr (DIRECT) { s1 = f16x2_scale(p.p1_amax[b]); a1 *= s1; }       // unscaled input rows: scaled as they are read
+            if constexpr (DIRECT) {
+                if (NS == 4 && p.t_bf16) s1 = p.row16_scale[b];                        // fp16 rows: stored with this power of two, the record is of the stored values
+                else { s1 = f16x2_scale(p.p1_amax[b]); a1 *= s1; }                     // unscaled input rows: scaled as they are read
+            }
             else s1 = p.p1_scale[b];
             const float inv_s1 = pow2_inverse(s1);
             const float bh1 = a1 + s1 * (p.w1x_norm * p.dmax);
@@ -384,6 +405,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
         s1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s1)));
         c2 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c2)));
         c3 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(c3)));
+        if constexpr (ROWS && NS == 4) {
+            if (p.out_bf16) {
+                // fp16 output rows: out' = so out with the power of two so that keeps |W3|_1 bound(H2) + max|b3| below 2^15, bound(H2) =
+                // 2^15 / s2 by the choice of s2 (c3 = u3 / s2).  Folded into the epilogue's factor and bias: out' = acc (c3 so) + b3 so.
+                const float bound2 = 32768.f * (c3 / p.u3);                             // = 2^15 / s2 >= bound(H2)
+                so = f16x2_scale(__float_as_uint(__fmaf_rn(p.w3_norm, bound2, p.b3_max)));
+                so = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(so)));
+                if (lane == 0 && valid && row0 == 0) p.row16_scale[b] = so;            // (one writer per window: its first strip)
+            }
+        }
         for (int i = lane; i < T2 * 32; i += 64) sbw[i] = sb2[i] * s1;           // read back by this wave only (LDS ops of a wave stay in order)
         if constexpr (L1F) {
             if (fmode) for (int i = lane; i < C1; i += 64) sb1w[i] = p.b1[i] * s1;
@@ -466,11 +497,16 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j = 0; j < ((ROWS && !DIRECT) ? 3 : 1); ++j)
 #pragma unroll
                 for (int j4 = 0; j4 < 4; ++j4) {
-                    if constexpr (NS == 1 && DIRECT) {
-                        if (p.t_bf16) {          // 4 bf16 values = 8 bytes at value offset 32 c + 4 qi(j4) of this lane's row
+                    if constexpr ((NS == 1 || NS == 4) && DIRECT) {
+                        if (p.t_bf16) {          // 4 bf16 / fp16 values = 8 bytes at value offset 32 c + 4 qi(j4) of this lane's row
                             const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(trow[j]) + (size_t)(c * 32 + 4 * qi(j4)) * 2);
-                            trw[j][j4] = f32x4{__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
-                                               __uint_as_float(h.y & 0xffff0000u)};
+                            if constexpr (NS == 1) {
+                                trw[j][j4] = f32x4{__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                                                   __uint_as_float(h.y & 0xffff0000u)};
+                            } else {             // widened exactly; finish_slice converts back to the same fp16 values (they ARE the plane)
+                                const f16x2 a = __builtin_bit_cast(f16x2, h.x), b_ = __builtin_bit_cast(f16x2, h.y);
+                                trw[j][j4] = f32x4{(float)a[0], (float)a[1], (float)b_[0], (float)b_[1]};
+                            }
                             continue;
                         }
                     }
@@ -482,11 +518,11 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
             for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    raw[j4][e] = DIRECT ? (F16 ? trw[0][j4][e] * s1 : trw[0][j4][e])
+                    raw[j4][e] = DIRECT ? ((F16 && !(NS == 4 && p.t_bf16)) ? trw[0][j4][e] * s1 : trw[0][j4][e])       // (fp16 rows arrive scaled)
                                         : __fmaf_rn(tw[2], trw[ROWS ? 2 : 0][j4][e], __fmaf_rn(tw[1], trw[ROWS ? 1 : 0][j4][e], __fmul_rn(tw[0], trw[0][j4][e])));
         };
         if constexpr (DIRECT) {
-            trow[0] = (NS == 1 && p.t_bf16)
+            trow[0] = ((NS == 1 || NS == 4) && p.t_bf16)
                           ? reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.P1) + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp * 2)
                           : reinterpret_cast<const float4*>(p.P1 + ((size_t)b * p.N + min(row0 + l31, p.N - 1)) * p.ldp);
             fetch(0);
@@ -1012,6 +1048,12 @@ __global__ __launch_bounds__(SAB_THREADS, 2) void sa_mlp_max_bf16_kernel(SaBP p)
                             if (NS == 1 && p.out_bf16) {
                                 unsigned short* o16 = reinterpret_cast<unsigned short*>(p.out) + ((size_t)b * p.N + row0 + 4 * half + pt) * p.ldo + 32 * u + l31;
                                 *o16 = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{o, 0.f}, bf16x2)) & 0xffffu);
+                            } else if (NS == 4 && p.out_bf16) {
+                                o = fminf(o * so, 65504.f);              // (exact power of two; the bound keeps it below 2^15 -- the clamp is for a broken contract)
+                                unsigned short* o16 = reinterpret_cast<unsigned short*>(p.out) + ((size_t)b * p.N + row0 + 4 * half + pt) * p.ldo + 32 * u + l31;
+                                const _Float16 h16 = (_Float16)o;
+                                *o16 = __builtin_bit_cast(unsigned short, h16);
+                                o = (float)h16;                          // the record is of the STORED values
                             } else
                             orow[(size_t)pt * p.ldo] = o;
                             if (ocm) ocm[pt] = o;
@@ -1236,13 +1278,16 @@ extern "C" int ev2h_tile_geometry(int C1, int C2, int C3, int planes, int out[10
     return ev2h_gemm_tile_geometry(planes, out + 6);
 }
 
-int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream);
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream, float* row16_scale = nullptr, float w3_norm = 0.f, float b3_max = 0.f);
 extern "C" int ev2h_fp_mlp(const ev2h_fp_desc* d, ev2h_stream_t stream) { return ev2h_fp_mlp_ex(d, 0, 0, stream); }
 
-// internal (forward.hip): t_bf16 -- the input rows of form (b) are bf16; out_bf16 -- the output rows are written as bf16.  BF16 mode only.
-int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream) {
+// internal (forward.hip): t_bf16 -- the input rows of form (b) are 16-bit values; out_bf16 -- the output rows are written as 16-bit
+// values.  BF16: bf16 values; F16 [r6] (with range records): fp16 values times the per-window power of two row16_scale[b] (written by the
+// out_bf16 call from the bound |W3|_1 bound(H2) + max|b3| -- w3_norm, b3_max --, read by the t_bf16 call).
+int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream, float* row16_scale, float w3_norm, float b3_max) {
     EV2H_CHECK_ARG(d && d->T && d->W2s && d->W3s && d->b2 && d->b3 && d->out);
-    EV2H_CHECK_ARG(!(t_bf16 || out_bf16) || (d->precision == EV2H_PREC_BF16 && (!out_bf16 || !d->out_cm) && (!t_bf16 || !d->nn_idx)));
+    EV2H_CHECK_ARG(!(t_bf16 || out_bf16) || ((d->precision == EV2H_PREC_BF16 || (d->precision == EV2H_PREC_F16 && row16_scale && d->t_amax)) &&
+                                             (!out_bf16 || !d->out_cm) && (!t_bf16 || !d->nn_idx)));
     EV2H_CHECK_ARG((d->nn_idx != nullptr) == (d->nn_w != nullptr));
     EV2H_CHECK_ARG(d->B > 0 && d->N > 0 && d->ldt >= d->C1 && (d->ldt % 4) == 0);
     const int ncols = d->out_cols > 0 ? d->out_cols : d->C3;
@@ -1254,6 +1299,7 @@ int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
     p.ncols = ncols; p.relu_out = d->no_relu_out ? 0 : 1; p.out_cm = d->out_cm;
     p.t_bf16 = t_bf16; p.out_bf16 = out_bf16;
+    p.row16_scale = row16_scale; p.w3_norm = w3_norm; p.b3_max = b3_max;
     p.out_cm_stride = d->out_cm_stride ? d->out_cm_stride : (size_t)ncols * d->N;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;
     p.nblk = ceil_div(d->B * p.S, SAB_WAVES);

@@ -453,10 +453,14 @@ class TEHNet(nn.Module):
         if not p:
             raise KeyError(name)
         off = p - ws.data_ptr()
-        if et.value == 1:             # the last forward stored this buffer as bf16 (BF16 mode: l0): widened here, `cnt` counts VALUES
+        if et.value in (1, 2):        # the last forward stored this buffer as 16-bit values (BF16 / F16 mode: l0): widened here, `cnt` counts VALUES
             if dtype != torch.float32:
-                raise TypeError(f"workspace buffer {name!r} holds bf16 values in this mode: ask for float32")
-            return ws[off:off + cnt.value * 2].view(torch.bfloat16).float()
+                raise TypeError(f"workspace buffer {name!r} holds {'bf16' if et.value == 1 else 'fp16'} values in this mode: ask for float32")
+            if et.value == 1:
+                return ws[off:off + cnt.value * 2].view(torch.bfloat16).float()
+            # F16: fp16 values times the window's power of two (workspace "p1scale" row 5): undone here, exactly
+            v = ws[off:off + cnt.value * 2].view(torch.float16).float().view(B, -1)
+            return (v / self.debug_buffer("p1scale").view(6, B)[5].view(B, 1)).view(-1)
         return ws[off:off + cnt.value * 4].view(dtype).clone()
 
 

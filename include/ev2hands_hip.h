@@ -425,6 +425,8 @@ typedef struct ev2h_sa_branch {
     float w2_unscale, w3_unscale;       /* see ev2h_sa_desc */
     float w1x_norm, w2_norm, b2_max;    /* F16X2 range bounds as in ev2h_sa_desc; filled by ev2h_pack_weights */
     float w1f_unscale, w1x_unscale;     /* F16X2: power-of-two plane factors of this branch's W1f and W1x (ev2h_sa_desc.w1f_unscale / w1x_unscale) */
+    float w3_norm, b3_max;              /* [ABI 8] max row L1 norm of W3, max |b3|: the bound of the chain's OUTPUT (F16: fp1's output rows are
+                                           stored as fp16 times a power of two chosen from it)                                       */
 } ev2h_sa_branch;
 
 typedef struct ev2h_sa_module {   /* one PointNetSetAbstractionMsg (pointnet2_utils.py:205-262)       */
@@ -603,12 +605,14 @@ int ev2h_profile_set(const char* tag, void** start_events, void** stop_events, i
 /* Debug access for parity tests: after ev2h_forward, device pointer of a named internal buffer in
  * `workspace` (e.g. "fps1", "gidx1_0", "l1cat", "l0", "sim", "hf8") and its element count; NULL if unknown.
  * "rng.<tensor>" (e.g. "rng.l0", "rng.p1b") = the F16X2 range record of that tensor, "p1scale" = the storage scales of the
- * five layer-1 tables [5][B] (enc.sa1, enc.sa2, left, right, fp1; only enc.sa2 and fp1 are computed in the default F16X2 path). */
+ * five layer-1 tables (enc.sa1, enc.sa2, left, right, fp1; only enc.sa2 and fp1 are computed in the default F16X2 path) and [ABI 8], row
+ * 5, of l0 when F16 stores it as fp16: float [6][B]. */
 const void* ev2h_workspace_buffer(void* workspace, int B, int N, const char* name, size_t* count);
 /* [ABI 8] The same with the element type: *elem_type = 0 for 4-byte elements (float32 / int32 / uint32, as documented per buffer),
- * 1 for bf16 -- `count` then still counts VALUES, stored 2 bytes each.  Today that is "l0" after a forward of the calling thread in
- * BF16 mode with the fused fp1 / segmentation-head / query-convolution forms (EV2H_L0_F32=1 keeps it float32): the one N-row,
- * 256-wide tensor of the path is then written and read as bf16.  A debugger that reads "l0" as float32 in that mode compares garbage
+ * 1 for bf16, 2 for fp16 TIMES the window's power of two ("p1scale" row 5: float [6][B]) -- `count` then still counts VALUES, stored
+ * 2 bytes each.  Today that is "l0" after a forward of the calling thread in BF16 (1) / F16 (2) mode with the fused fp1 /
+ * segmentation-head / query-convolution forms (EV2H_L0_F32=1 keeps it float32): the one N-row, 256-wide tensor of the path is then
+ * written and read as 16-bit values; in F16 its range record "rng.l0" is the maximum of the STORED values.  A debugger that reads "l0" as float32 in that mode compares garbage
  * (ADVICE r5); ev2hands_amd's TEHNet.debug_buffer widens it. */
 const void* ev2h_workspace_buffer_ex(void* workspace, int B, int N, const char* name, size_t* count, int* elem_type);
 

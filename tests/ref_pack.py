@@ -504,6 +504,8 @@ class PackedWeights:
         br.w1x_norm = 0.0
         br.w2_norm = _l1(W0) * (1 + 1e-6)
         br.b2_max = float(np.abs(b0).max()) * (1 + 1e-6)
+        br.w3_norm = _l1(W4p) * (1 + 1e-6)
+        br.b3_max = float(np.abs(b4p).max()) * (1 + 1e-6)
         i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(W0, W4p, self.ns)
         br.W2s = self._dev_bytes("clsm.W2s", i2)
         br.W3s = self._dev_bytes("clsm.W3s", i3)
@@ -525,6 +527,8 @@ class PackedWeights:
         br.w1x_norm = 0.0
         br.w2_norm = _l1(Ws[1]) * (1 + 1e-6)
         br.b2_max = float(np.abs(bs[1]).max()) * (1 + 1e-6)
+        br.w3_norm = _l1(Ws[2]) * (1 + 1e-6)
+        br.b3_max = float(np.abs(bs[2]).max()) * (1 + 1e-6)
         i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(Ws[1], Ws[2], self.ns)
         br.W2s = self._dev_bytes(n + ".W2s", i2)
         br.W3s = self._dev_bytes(n + ".W3s", i3)
@@ -559,6 +563,8 @@ class PackedWeights:
             br.w1x_unscale = plane_unscale(Ws[0][:, nfeat:], self.ns)
             br.w2_norm = _l1(Ws[1]) * (1 + 1e-6)
             br.b2_max = float(np.abs(bs[1]).max()) * (1 + 1e-6)
+            br.w3_norm = _l1(Ws[2]) * (1 + 1e-6)
+            br.b3_max = float(np.abs(bs[2]).max()) * (1 + 1e-6)
             if self.ns:
                 i2, i3, br.w2_unscale, br.w3_unscale = sa_bf16_images(Ws[1], Ws[2], self.ns)
                 br.W2s = self._dev_bytes(n + ".W2s", i2)

@@ -973,7 +973,7 @@ def test_debug_buffer_knows_what_l0_holds_in_bf16_mode():
     xyz = synth.synth_cloud("E", B, C, N, seed).cuda()
     inits = synth.fps_inits(B, N, seed)
     l0 = {}
-    for prec in ("f32", "bf16", "f16x2"):
+    for prec in ("f32", "bf16", "f16x2", "f16"):
         net, _sd, _assets = make_net(C, seed, precision=prec)
         net.net.fps_init = inits
         with torch.no_grad():
@@ -988,3 +988,6 @@ def test_debug_buffer_knows_what_l0_holds_in_bf16_mode():
     e = rel(l0["bf16"], l0["f32"])
     print(f"bf16-stored l0 against the exact-fp32 mode's: {e:.2e}")
     assert 1e-5 < e < 2e-2
+    e16 = rel(l0["f16"], l0["f32"])          # fp16 values times the window's power of two (workspace "p1scale" row 5): undone by debug_buffer
+    print(f"fp16-stored l0 (F16 mode) against the exact-fp32 mode's: {e16:.2e}")
+    assert 1e-6 < e16 < 3e-3

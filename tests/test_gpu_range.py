@@ -132,7 +132,7 @@ def test_range_records_hold_the_exact_maxima():
         assert torch.equal(got, want), (rec, got, want)
     # layer-1 tables are stored scaled: scale * (max |table| + |W1x|_1 r) stays below 2^15 and the record is the stored maximum
     # (enc.sa1 and the regressors' sa1 read the raw feature rows: their layer 1 runs on the matrix pipe and has no table -- slots 0, 2, 3)
-    ps = dbg("p1scale").view(5, B)
+    ps = dbg("p1scale").view(6, B)
     for k, (rec, buf, shape) in ((1, ("p1b", "P1b", (B, 512, 256))), (4, ("fp1t", "fp1T", (B, 512, 128)))):
         got = dbg("rng." + rec).view(torch.float32)[:B]
         want = dbg(buf).view(shape).abs().amax((1, 2))

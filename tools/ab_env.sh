@@ -3,7 +3,7 @@
 #   PRECS="f16x2 bf16" bash tools/ab_env.sh EV2H_ATTN_UNFUSED_ZSUM [extra bench args...]
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 VAR=$1; shift
-ARGS="--steps ${STEPS:-100} --warmup 5 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-host-io $*"
+ARGS="--steps ${STEPS:-100} --warmup 5 --no-legs --no-latency --no-cpu-baseline --no-traffic --no-selfcheck --no-host-io --no-sustained $*"
 for r in $(seq 1 ${ROUNDS:-2}); do
   for prec in ${PRECS:-f16x2 bf16}; do
     for v in "" 1; do
