@@ -36,7 +36,7 @@ class SaDesc(C.Structure):
                 ("p1_scale", vp), ("p1_amax", vp), ("w1x_norm", C.c_float), ("dmax", C.c_float), ("w2_norm", C.c_float), ("b2_max", C.c_float),
                 ("out_amax", vp), ("feat", vp), ("ldf", ci), ("W1f", vp), ("ldw1f", ci), ("b1", vp), ("nfeat", ci),
                 ("feat_amax", vp), ("w1f_norm", C.c_float), ("b1_max", C.c_float), ("w1f_unscale", C.c_float), ("w1x_unscale", C.c_float),
-                ("xyz_out", vp), ("xyz_ld", ci)]
+                ("xyz_out", vp), ("xyz_ld", ci), ("S_total", ci), ("s_off", ci)]
 
 
 class FpDesc(C.Structure):

@@ -91,7 +91,7 @@ static inline void prof_end(const char* tag, ev2h_stream_t st) {
 // its own stream on that device.
 struct SideCtx {
     hipStream_t stream = nullptr;
-    static constexpr int NEV = 10;
+    static constexpr int NEV = 14;     // (10 .. 13: the chunks of enc.sa1's sampling)
     hipEvent_t ev[NEV] = {};
     int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
 };
@@ -204,6 +204,11 @@ extern "C" int ev2h_shader_clock_probe(ev2h_stream_t stream, int spin_us, unsign
 
 // ---------------------------------------------------------------------------------------- small kernels
 // internal entry points of other translation units (not part of the C ABI)
+size_t ev2h_fps_state_ld(int N);
+int ev2h_fps_multi_chunk(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init, int32_t* const* idx, float* const* ctr4,
+                         int s_begin, int s_end, float* state, ev2h_stream_t stream);
+int ev2h_ball_query_range(const float* pts4, const float* ctr4, int B, int N, int S, int s_off, int s_cnt, int nrad, const double* radius,
+                          const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream);
 bool ev2h_gemm_bf16_zsum_supported(const ev2h_gemm_desc* d);
 int ev2h_gemm_bf16_zsum(const ev2h_gemm_desc* d, const float* key_pm, float* zpart, int x_bf16, ev2h_stream_t stream, const float* x_scale = nullptr);
 int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_t stream, float* row16_scale = nullptr, float w3_norm = 0.f, float b3_max = 0.f);
@@ -314,6 +319,7 @@ static void build_layout(Layout& L, int B, int N) {
         L.add(kHandNames[h][9], b * 1024);
     }
     L.add("ranges", (size_t)R_COUNT * b);       // F16X2 range records (uint32 [R_COUNT][B]) ...
+    L.add("fps_state", b * 3 * ev2h_fps_state_ld(N));      // chunked sampling of small batches: running minima between the launches
     L.add("p1scale", 6 * b);                    // ... and the storage scales of the five layer-1 tables (float [5][B]) + [5]: of l0 when it is stored as fp16 (F16)
 }
 
@@ -400,7 +406,7 @@ static bool bf16_direct_layer1(int precision, const ev2h_sa_module& m) {
 static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, const float* pts4, const float* ctr4, int32_t* const* gidx,
                        const int32_t* cnt, int B, int Npts, const float* P1, float* out, int ldo, ev2h_stream_t st, bool ranges,
                        const uint32_t* p1_amax, const float* p1_scale, uint32_t* out_amax, const float* feat = nullptr, int nfeat = 0,
-                       const uint32_t* feat_amax = nullptr, float* xyz_out = nullptr, int xyz_ld = 0) {
+                       const uint32_t* feat_amax = nullptr, float* xyz_out = nullptr, int xyz_ld = 0, int s_off = 0, int s_cnt = 0) {
     int c1sum = 0;
     for (int i = 0; i < m.nbranch; ++i) c1sum += m.br[i].C1;
     int coff1 = 0, coff3 = 0;
@@ -411,6 +417,7 @@ static int sa_branches(int precision, const char* tag, const ev2h_sa_module& m, 
         d.W1x = br.W1x; d.W2 = br.W2; d.b2 = br.b2; d.W3 = br.W3; d.b3 = br.b3;
         d.out = out + coff3; d.ldo = ldo;
         d.B = B; d.Npts = Npts; d.S = m.npoint; d.K = br.K; d.C1 = br.C1; d.C2 = br.C2; d.C3 = br.C3;
+        if (s_cnt > 0) { d.S = s_cnt; d.S_total = m.npoint; d.s_off = s_off; }      // the centroids [s_off, s_off + s_cnt) of every window
         d.precision = precision; d.W2s = br.W2s; d.W3s = br.W3s; d.w2_unscale = br.w2_unscale; d.w3_unscale = br.w3_unscale;
         const bool direct = feat && bf16_direct_layer1(precision, m);
         if (direct) {
@@ -614,18 +621,40 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
     }
     if (!bf16_direct_layer1(prec, w->sa1)) RUN(sa_table(prec_sa, w->sa1, ws.f("feat8"), 8, B, N, ws.f("P1a"), sx, ws.r(R_FEAT), ws.r(R_P1A), ws.p1scale(0)));
     if (fork) EV2H_CHECK_HIP(hipEventRecord(side->ev[5], side->stream));
+    // [r6] enc.sa1's sampling is 512 DEPENDENT arg-max steps on 3 workgroups per window -- at 16 windows of 8192 points 0.49 ms on 48
+    // of 256 CUs (a fifth of the forward), at 8 windows of 2048 points 0.25 of 1.25 ms -- and everything else waited for it.  The 512
+    // centroids are now drawn in four launches of 128 on the SIDE stream (ev2h_fps_multi_chunk: the running minima travel through
+    // the workspace; the same arg-max sequence, identical indices), and the caller's stream runs the ball query and the three fused
+    // set-abstraction launches of each quarter as soon as it is drawn (ev2h_sa_desc.s_off): 3/4 of enc.sa1 runs beside the sampling.
+    // Same kernels on the same groups: bit-identical outputs.  Measured (tools/debug/chunk_check.py, profiles/r6_fps_chunks*.txt):
+    // 16 x 8192: 6 969 -> 7 612 windows/s, 8 x 2048 hipGraph 1.177 -> 1.113 ms, 32 x 2048 +4 %, 64 x 8192 +2-3 %, 256 x 2048 +1.0 %;
+    // NOT below 8 windows (the twelve extra launches cost more than the overlap: -1.5 .. -3 %) and not where the sampling already
+    // fills the chip with one staged window per CU (128 x 8192: -1.5 %).
+    // EV2H_FPS_CHUNKS=0: A/B switch (one launch); = n > 1: chunk at any batch up to n sampling workgroups (tuning).
+    static const int chunk_env = [] { const char* e = getenv("EV2H_FPS_CHUNKS"); return e ? atoi(e) : -1; }();
+    constexpr int FPS_CHUNKS = 4;
+    const int chunk_max_wg = chunk_env > 1 ? chunk_env : (N <= 2048 ? 0x7fffffff : 256), chunk_min_b = chunk_env > 1 ? 1 : 8;
+    const bool chunked = fork && chunk_env != 0 && B >= chunk_min_b && 3 * B <= chunk_max_wg && bf16_direct_layer1(prec, w->sa1) && w->sa1.npoint % FPS_CHUNKS == 0;
     {
         const int S[3] = {512, 128, 128};
         const int64_t* init[3] = {fps_init, fps_init + 2 * (size_t)B, fps_init + 3 * (size_t)B};
         int32_t* idx[3] = {ws.i("fps1"), ws.i("fpsmL"), ws.i("fpsmR")};
         float* ctr[3] = {ws.f("ctr1"), ws.f("ctrmL"), ws.f("ctrmR")};
-        RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
+        if (!chunked) {
+            RUN(ev2h_fps_multi(ws.f("pts4"), B, N, 3, S, init, idx, ctr, st));
+        } else {
+            const int q = w->sa1.npoint / FPS_CHUNKS;
+            for (int c = 0; c < FPS_CHUNKS; ++c) {          // (the regressors' 128-centroid samplings finish inside the first launch)
+                RUN(ev2h_fps_multi_chunk(ws.f("pts4"), B, N, 3, S, init, idx, ctr, c * q, (c + 1) * q, ws.f("fps_state"), sd));
+                EV2H_CHECK_HIP(hipEventRecord(side->ev[10 + c], side->stream));
+            }
+        }
     }
     // fork 1: everything that needs only COORDINATES runs on the side stream, under the MFMA-bound set-abstraction kernels of
     // enc.sa1 on the caller's stream (it used to sit between them on the critical path): the sampling and the ball query of
     // enc.sa2 (its input points are enc.sa1's centroids), the 3-NN selection of fp1 (raw cloud against those centroids), then
     // both hands' ball queries.  Same kernels, same inputs: bit-identical.
-    if (fork) {
+    if (fork && !chunked) {                                   // (chunked: the sampling itself ran on the side stream)
         EV2H_CHECK_HIP(hipEventRecord(side->ev[0], (hipStream_t)st));
         EV2H_CHECK_HIP(hipStreamWaitEvent(side->stream, side->ev[0], 0));
     }
@@ -659,10 +688,20 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         double rad[3]; int ns[3];
         int32_t* gi[3] = {ws.i("gidx1_0"), ws.i("gidx1_1"), ws.i("gidx1_2")};
         for (int i = 0; i < 3; ++i) { rad[i] = m.br[i].radius; ns[i] = m.br[i].K; }
-        RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
-        if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
-        RUN(sa_branches(prec_sa, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
-                        ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C, ws.r(R_FEAT)));
+        if (!chunked) {
+            RUN(ev2h_ball_query(ws.f("pts4"), ws.f("ctr1"), B, N, 512, 3, rad, ns, gi, ws.i("cnt1"), st));
+            if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[5], 0));          // the table is written
+            RUN(sa_branches(prec_sa, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
+                            ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C, ws.r(R_FEAT)));
+        } else {
+            const int q = m.npoint / FPS_CHUNKS;
+            for (int c = 0; c < FPS_CHUNKS; ++c) {          // quarter c: as soon as its centroids are drawn
+                EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[10 + c], 0));
+                RUN(ev2h_ball_query_range(ws.f("pts4"), ws.f("ctr1"), B, N, 512, c * q, q, 3, rad, ns, gi, ws.i("cnt1"), st));
+                RUN(sa_branches(prec_sa, "sa1", m, ws.f("pts4"), ws.f("ctr1"), gi, ws.i("cnt1"), B, N, ws.f("P1a"), ws.f("l1cat"), 576, st, ws.ranges_on,
+                                ws.r(R_P1A), ws.p1scale(0), ws.r(R_L1A), ws.f("feat8"), C, ws.r(R_FEAT), nullptr, 0, c * q, q));
+            }
+        }
     }
     // ---- enc.sa2 (TEHNet.py:180) on the 512 sampled points (sampling + ball query: fork 1 above)
     {

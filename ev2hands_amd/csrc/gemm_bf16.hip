@@ -979,8 +979,9 @@ int launch_go_pipe(const GemmBP& p, const char* Ws, hipStream_t st) {
 
 template <int NS>
 int launch_go(const GemmBP& p, const char* Ws, hipStream_t st) {
-    static const bool no_tap3 = getenv("EV2H_GEMM_NO_TAP3") != nullptr;       // A/B switch
-    if (p.taps == 3 && !no_tap3 && p.Kc % GB_BK == 0 && p.rows_per_seq % GB_BM == 0 && p.M % p.rows_per_seq == 0)
+    // (the tap-reuse kernel for the shapes that tile; every other k = 3 shape -- N % 128 != 0 -- takes the plain K loop below, which the
+    //  odd-N end-to-end cases exercise: the EV2H_GEMM_NO_TAP3 switch of rounds 2-5 is retired)
+    if (p.taps == 3 && p.Kc % GB_BK == 0 && p.rows_per_seq % GB_BM == 0 && p.M % p.rows_per_seq == 0)
         return launch_go_t<NS, true>(p, Ws, st);
     // (same sums in the same order in all three tilings: test_gpu_ops.py::test_gemm_small_grids_bit_identical compares them through M)
     if (p.nblk <= 64 && p.rowmax_rows == 0 && p.taps == 1) return launch_go_small<NS>(p, Ws, st);   // quarter-size tiles

@@ -56,6 +56,11 @@ struct FpsJobs {
     const int64_t* init[3];
     int32_t* idx[3];
     float4* ctr[3];
+    // chunked sampling [r6] (ev2h_fps_multi_chunk): this launch draws samples [s_begin, s_end) of every job (clipped to the job's S);
+    // the running minima and the next start index travel between the launches of one sampling in `state`
+    // (float [B][njobs][state_ld]: state_ld - 4 minima in the thread order p = j * THREADS + tid, then the index)
+    int s_begin, s_end;
+    float* state; int state_ld;
 };
 
 // THREADS = 256 with the window's points also in LDS (N <= 8192: the winner's coordinates are one LDS read away); windows beyond
@@ -109,8 +114,16 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__
     int far = (int)jobs.init[job][b];
     int32_t* oidx = jobs.idx[job] + (size_t)b * S;
     float4* octr = jobs.ctr[job] + (size_t)b * S;
+    const int i_begin = min(jobs.s_begin, S), i_end = min(jobs.s_end, S);
+    if (i_begin >= i_end) return;                        // (workgroup-uniform: this job was finished by an earlier chunk)
+    float* st = jobs.state ? jobs.state + ((size_t)b * jobs.njobs + job) * jobs.state_ld : nullptr;
+    if (i_begin > 0) {                                   // resume: the minima as the previous chunk left them
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) md[j] = st[j * THREADS + tid];
+        far = reinterpret_cast<const int*>(st)[jobs.state_ld - 4];
+    }
 
-    for (int i = 0; i < S; ++i) {
+    for (int i = i_begin; i < i_end; ++i) {
         if constexpr (!REG_PTS) asm volatile("" : "+v"(tid_v));
         const float4 c = LDS_PTS ? spts[far] : src[far];
         if (tid == 0) { oidx[i] = far; octr[i] = c; }
@@ -161,6 +174,11 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(const float4* __restrict__
         for (int w = 1; w < NW; ++w) { const unsigned long long kw = skey[i & 1][w]; k0 = k0 > kw ? k0 : kw; }
         far = (int)(0xffffffffu - (unsigned)(k0 & 0xffffffffull));
     }
+    if (i_end < S) {                                     // to be continued by the next chunk
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) st[j * THREADS + tid] = md[j];
+        if (tid == 0) reinterpret_cast<int*>(st)[jobs.state_ld - 4] = far;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- ball query
@@ -172,6 +190,7 @@ struct BallArgs {
     int32_t* cnt;   // [B][S][nrad] (may be null)
     int cpw;        // centroids per workgroup (multiple of 4: one per wave and round)
     int nchunk;     // workgroups per window = ceil(S / cpw); the grid is 1-D: nchunk * B workgroups
+    int s_off, s_cnt;   // the centroids [s_off, s_off + s_cnt) of every window (ev2h_ball_query_range; the whole set: 0, S)
 };
 
 constexpr int BALL_CTR_PER_WG = 4, BALL_UNR = 4;      // one centroid per wave
@@ -192,8 +211,8 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float4* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* src = pts4 + (size_t)b * N;
     (void)tid;
-    const int s_begin = (L - b * a.nchunk) * a.cpw;
-    for (int s = s_begin + wave; s < s_begin + a.cpw && s < S; s += 4) {
+    const int s_begin = a.s_off + (L - b * a.nchunk) * a.cpw;
+    for (int s = s_begin + wave; s < s_begin + a.cpw && s < a.s_off + a.s_cnt; s += 4) {
         const float4 c = ctr4[(size_t)b * S + s];
         int cnt[3] = {0, 0, 0};
         int first[3] = {0, 0, 0};
@@ -354,18 +373,40 @@ extern "C" int ev2h_prep_points(float* xyz_cm, int B, int C, int N, int mhlnes, 
     return EV2H_OK;
 }
 
+// floats of sampling state per (window, job) for ev2h_fps_multi_chunk: the padded thread layout of the kernel that samples N points + the index
+size_t ev2h_fps_state_ld(int N) {
+    const int threads = N <= 2048 ? 256 : (N <= 8192 ? 512 : 1024);
+    const int ppt = N <= 256 ? 1 : N <= 512 ? 2 : N <= 1024 ? 4 : N <= 2048 ? 8 : N <= 4096 ? 8 : N <= 8192 ? 16 : N <= 16384 ? 16 : 32;
+    return (size_t)threads * ppt + 4;
+}
+
+int ev2h_fps_multi_chunk(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init, int32_t* const* idx, float* const* ctr4,
+                         int s_begin, int s_end, float* state, ev2h_stream_t stream);
+
 extern "C" int ev2h_fps_multi(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init,
                               int32_t* const* idx, float* const* ctr4, ev2h_stream_t stream) {
+    return ev2h_fps_multi_chunk(pts4, B, N, njobs, S, init, idx, ctr4, 0, 0x7fffffff, nullptr, stream);
+}
+
+// internal (forward.hip) [r6]: samples [s_begin, s_end) of every job in this launch; `state` (B * njobs * ev2h_fps_state_ld(N) floats)
+// carries a sampling from one launch to the next -- the same sequence of arg-max steps as one launch, identical indices.  A small
+// batch leaves most of the chip idle for the 512 dependent steps of enc.sa1's sampling: in chunks, the ball query and the fused set
+// abstraction of the centroids already drawn run beside the rest of the sampling (ev2h_forward).
+int ev2h_fps_multi_chunk(const float* pts4, int B, int N, int njobs, const int* S, const int64_t* const* init, int32_t* const* idx, float* const* ctr4,
+                         int s_begin, int s_end, float* state, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts4 && S && init && idx && ctr4);
     EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 32768 && njobs >= 1 && njobs <= 3);
+    EV2H_CHECK_ARG(s_begin >= 0 && s_end > s_begin);
     FpsJobs jobs{};
     jobs.njobs = njobs;
+    jobs.s_begin = s_begin; jobs.s_end = s_end; jobs.state = state; jobs.state_ld = (int)ev2h_fps_state_ld(N);
     for (int j = 0; j < njobs; ++j) {
         EV2H_CHECK_ARG(S[j] > 0 && init[j] && idx[j] && ctr4[j]);
         jobs.S[j] = S[j];
         jobs.init[j] = init[j];
         jobs.idx[j] = idx[j];
         jobs.ctr[j] = (float4*)ctr4[j];
+        EV2H_CHECK_ARG(state || (s_begin == 0 && s_end >= S[j]));      // a sampling that spans launches needs its state buffer
     }
     dim3 grid(B, njobs);
     const size_t lds = (size_t)N * sizeof(float4);
@@ -399,10 +440,19 @@ extern "C" int ev2h_fps(const float* pts4, int B, int N, int S, const int64_t* i
     return ev2h_fps_multi(pts4, B, N, 1, &S, &init, &idx, &ctr4, stream);
 }
 
+int ev2h_ball_query_range(const float* pts4, const float* ctr4, int B, int N, int S, int s_off, int s_cnt, int nrad, const double* radius,
+                          const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream);
+
 extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int N, int S, int nrad, const double* radius,
                                const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream) {
+    return ev2h_ball_query_range(pts4, ctr4, B, N, S, 0, S, nrad, radius, nsample, gidx, cnt, stream);
+}
+
+// internal (forward.hip) [r6]: the same for the centroids [s_off, s_off + s_cnt) of every window (arrays indexed as for the whole set)
+int ev2h_ball_query_range(const float* pts4, const float* ctr4, int B, int N, int S, int s_off, int s_cnt, int nrad, const double* radius,
+                          const int* nsample, int32_t* const* gidx, int32_t* cnt, ev2h_stream_t stream) {
     EV2H_CHECK_ARG(pts4 && ctr4 && radius && nsample && gidx);
-    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 32768 && S > 0 && nrad >= 1 && nrad <= 3);
+    EV2H_CHECK_ARG(B > 0 && N > 0 && N <= 32768 && S > 0 && nrad >= 1 && nrad <= 3 && s_off >= 0 && s_cnt > 0 && s_off + s_cnt <= S);
     BallArgs a{};
     a.nrad = nrad;
     for (int i = 0; i < nrad; ++i) {
@@ -414,7 +464,8 @@ extern "C" int ev2h_ball_query(const float* pts4, const float* ctr4, int B, int 
     }
     a.cnt = cnt;
     a.cpw = BALL_CTR_PER_WG;
-    a.nchunk = ceil_div(S, a.cpw);
+    a.s_off = s_off; a.s_cnt = s_cnt;
+    a.nchunk = ceil_div(s_cnt, a.cpw);
     ball_query_kernel<<<dim3((unsigned)a.nchunk * (unsigned)B), 256, 0, (hipStream_t)stream>>>((const float4*)pts4, (const float4*)ctr4, N, S, a);
     EV2H_CHECK_LAUNCH();
     return EV2H_OK;

@@ -272,6 +272,7 @@ extern "C" int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     EV2H_CHECK_ARG((d->ldp % 4) == 0);
     EV2H_CHECK_ARG(!d->xyz_out || (d->xyz_ld >= 8 && (d->xyz_ld % 4) == 0));
     if (d->precision != EV2H_PREC_F32) return ev2h_sa_mlp_max_bf16(d, stream);
+    EV2H_CHECK_ARG(d->s_off == 0 && (d->S_total == 0 || d->S_total == d->S));      // (centroid sub-ranges: the plane-mode kernels only)
     // exact fp32: layer 1 is the gathered table row + the relative-coordinate term; the raw-feature form (ev2h_sa_desc.feat
     // without a table) exists on the matrix pipe only
     if (!d->P1) {

@@ -40,6 +40,9 @@ struct SaBP {
     const char* W3s; const float* b3;
     float* out; int ldo;
     int B, Npts, S, K;
+    // a launch may cover the centroids [s_off, s_off + S) of every window of arrays laid out for S_total centroids per window
+    // (ev2h_sa_desc.S_total / s_off [r6]: chunks of enc.sa1 run beside the rest of its farthest-point sampling); S_total == S: all
+    int S_total, s_off;
     int nblk;
     const int32_t* cnt; int cnt_ld;       // optional distinct-neighbour counts (ev2h_sa_desc.cnt)
     float u2, u3;                         // power-of-two unscale factors of the W2s / W3s planes (ev2h_sa_desc.w2_unscale)
@@ -364,13 +367,15 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
     const bool valid = g < ngroups;
     const int gg = valid ? g : ngroups - 1;
     const int b = gg / p.S;
+    // index of this group in the caller's arrays (centroids, index lists, counts, output rows)
+    const size_t gf = ROWS ? (size_t)gg : (size_t)b * p.S_total + p.s_off + (gg - b * p.S);
     float mrun[T3];
 #pragma unroll
     for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
 
     float4 ctr = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* gi = nullptr;
-    if constexpr (!ROWS) { ctr = p.ctr4[gg]; gi = p.gidx + (size_t)gg * p.K + sw * 32; }
+    if constexpr (!ROWS) { ctr = p.ctr4[gf]; gi = p.gidx + gf * p.K + sw * 32; }
     const int row0 = ROWS ? (gg - b * p.S) * 32 : 0;          // ROWS: first point of this strip inside its window
     unsigned am = 0u;
     // f16x2 range: with P1' = s1 P1 (table stored scaled) and d' = s1 d the layer-1 output is H1' = s1 H1 <= a1 + s1 |W1x|_1 dmax
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
     // padding cannot change the max and are skipped.  In the streamed variant every wave still walks the tile steps of the
     // workgroup's longest group (DMA pieces and barriers), without computing.
     int my_strips = ROWS ? 1 : p.K >> 5;
-    if (!ROWS && p.cnt) my_strips = min(my_strips, max(1, (p.cnt[(size_t)gg * p.cnt_ld] + 31) >> 5));
+    if (!ROWS && p.cnt) my_strips = min(my_strips, max(1, (p.cnt[gf * p.cnt_ld] + 31) >> 5));
     if (spg > 1) my_strips = (valid && sw < my_strips) ? 1 : 0;      // spread: this wave owns strip sw of its group (or nothing)
     int nstrips = my_strips;
     if constexpr (!RES && !ROWS) {
@@ -1106,14 +1111,14 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
             const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
             if (valid && half == 0 && sw == 0) {
                 const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
-                p.out[(size_t)g * p.ldo + 32 * u + l31] = o;
+                p.out[gf * p.ldo + 32 * u + l31] = o;
                 am = max(am, __float_as_uint(o));
             }
         }
     }
     if constexpr (!ROWS) {
         if (p.xyz_out && valid && sw == 0 && lane < 8)
-            p.xyz_out[(size_t)g * p.xyz_ld + lane] = lane == 0 ? ctr.x : lane == 1 ? ctr.y : lane == 2 ? ctr.z : 0.f;
+            p.xyz_out[gf * p.xyz_ld + lane] = lane == 0 ? ctr.x : lane == 1 ? ctr.y : lane == 2 ? ctr.z : 0.f;
     }
     if constexpr (F16) {
         // Range record of the output (ev2hands_hip.h "Range records"): amax[b] = max over the window's groups.  One device-scope
@@ -1297,6 +1302,7 @@ int ev2h_fp_mlp_ex(const ev2h_fp_desc* d, int t_bf16, int out_bf16, ev2h_stream_
     p.P1 = d->T; p.ldp = d->ldt; p.nn_idx = d->nn_idx; p.nn_w = d->nn_w; p.N = d->N;
     p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->S; p.S = ceil_div(d->N, 32); p.K = 32;
+    p.S_total = p.S; p.s_off = 0;
     p.ncols = ncols; p.relu_out = d->no_relu_out ? 0 : 1; p.out_cm = d->out_cm;
     p.t_bf16 = t_bf16; p.out_bf16 = out_bf16;
     p.row16_scale = row16_scale; p.w3_norm = w3_norm; p.b3_max = b3_max;
@@ -1328,6 +1334,8 @@ int ev2h_sa_mlp_max_bf16(const ev2h_sa_desc* d, ev2h_stream_t stream) {
     p.P1 = d->P1; p.ldp = d->ldp; p.pts4 = (const float4*)d->pts4; p.ctr4 = (const float4*)d->ctr4; p.gidx = d->gidx;
     p.W1x = (const float4*)d->W1x; p.W2s = (const char*)d->W2s; p.b2 = d->b2; p.W3s = (const char*)d->W3s; p.b3 = d->b3;
     p.out = d->out; p.ldo = d->ldo; p.B = d->B; p.Npts = d->Npts; p.S = d->S; p.K = d->K;
+    p.S_total = d->S_total > 0 ? d->S_total : d->S; p.s_off = d->s_off;
+    EV2H_CHECK_ARG(p.s_off >= 0 && p.s_off + p.S <= p.S_total);
     p.cnt = d->cnt; p.cnt_ld = d->cnt_ld;
     p.xyz_out = d->xyz_out; p.xyz_ld = d->xyz_ld;
     p.u2 = d->w2_unscale > 0.f ? d->w2_unscale : 1.f; p.u3 = d->w3_unscale > 0.f ? d->w3_unscale : 1.f;

@@ -249,6 +249,11 @@ typedef struct ev2h_sa_desc {
      * raw-xyz columns of the group-all layer that consumes `out` (model/pointnet2_utils.py:155 concatenates [xyz, features]; the
      * forward's buffers hold [features | xyz | pad]), which used to take a launch of their own per module.  xyz_ld % 4 == 0.     */
     float* xyz_out; int xyz_ld;
+    /* optional [ABI 8], 16-bit plane precisions: this launch covers the centroids [s_off, s_off + S) of every window, while ctr4, gidx, cnt,
+     * out and xyz_out are laid out for S_total centroids per window (S_total = 0: S, the whole set).  ev2h_forward draws enc.sa1's
+     * 512 centroids in four chunks when the batch is too small to fill the chip, and runs the grouping + the fused MLP of the
+     * centroids already drawn beside the rest of the sampling (512 dependent steps on a fraction of the CUs). */
+    int S_total, s_off;
 } ev2h_sa_desc;
 int ev2h_sa_mlp_max(const ev2h_sa_desc* d, ev2h_stream_t stream);
 

@@ -752,7 +752,7 @@ def test_two_stream_fork_is_bit_identical(tmp_path):
 # settled and whose path nothing else needs.  Each remaining one runs the whole forward in a child
 # process and is compared with the default path -- bit-identical where the arithmetic is the same, <= 1e-5 where the switch
 # re-associates sums (the un-fused forms), selections and argmax identical in every case.
-AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_SA_STREAMED", "1", True), ("EV2H_GEMM_NO_TAP3", "1", True),
+AB_SWITCHES = [("EV2H_TWO_STREAMS", "0", True), ("EV2H_SA_STREAMED", "1", True), ("EV2H_FPS_CHUNKS", "100000", True),     # (3 windows: one launch by default -- the value forces the chunked sampling of 8+ windows)
                ("EV2H_FP1_UNFUSED", "1", False), ("EV2H_CLS_UNFUSED", "1", False), ("EV2H_ATTN_UNFUSED_ZSUM", "1", False),
                ("EV2H_L1_TABLE", "1", False), ("EV2H_L0_F32", "1", True)]       # (EV2H_L0_F32 acts in BF16 only: see test_bf16_l0_storage below)
 
