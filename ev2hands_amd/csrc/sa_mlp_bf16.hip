@@ -129,7 +129,16 @@ struct SaBCfg {
     // W1x in fp32 (12 B per channel, padded); BF16: the layer-1 A tile [C1][16 k] in bf16; F16X2: two A tiles per channel row
     // ([wh | wh], [wl | 0]: 64 B) + the b1 bias times each wave's window scale
     // BF16X3: three A tiles per channel row ([w0 | w0], [w1 | w1], [w2 | w0]: 96 B) + the b1 bias
-    static constexpr int W1B = (NS == 1 || NS == 4) ? C1 * 32 : F16 ? C1 * 64 + SAB_WAVES * C1 * 4 : C1 * 96 + C1 * 4;
+    // [r6] the L1F A rows carry a 16-byte pad (80 / 112 instead of 64 / 96 bytes): at 64 bytes per row the 32 rows a fragment read
+    // touches fall on 4 of the LDS's 256-byte bank windows eight deep -- SQ_LDS_BANK_CONFLICT 15.6 M cycles per launch in the
+    // feature-row form against 0 in the table form (profiles/r5_pmc_sq_f16x2.txt); padded like the weight tiles they are conflict free.
+    // EV2H_BUILD_DEFS=-DEV2H_L1F_NO_PAD: the unpadded rows (A/B).
+#ifdef EV2H_L1F_NO_PAD
+    static constexpr int RSA = (NS == 3) ? 96 : 64;
+#else
+    static constexpr int RSA = (NS == 3) ? 112 : 80;
+#endif
+    static constexpr int W1B = (NS == 1 || NS == 4) ? C1 * 32 : F16 ? C1 * RSA + SAB_WAVES * C1 * 4 : C1 * RSA + C1 * 4;
     // range-record combine (F16X2, end of a group): 8 x (window, max) in the streamed variants, REC_SLOTS per-window running maxima
     // in the resident one -- see the kernel's epilogue
     static constexpr int REC_SLOTS = 64;
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
     const bool hasfeat = sab_split_forms<NS>() ? (MODE == 3) : (p.feat != nullptr);
     const bool fmode = L1F && hasfeat;                         // (uniform)
     // F16X2 feature mode: s1 b1 of this wave's window; BF16X3 feature mode: b1 (one copy)
-    float* sb1w = F16 ? reinterpret_cast<float*>(smem + WBYTES + C1 * 64) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * 96);
+    float* sb1w = F16 ? reinterpret_cast<float*>(smem + WBYTES + C1 * Cfg::RSA) + wave * C1 : reinterpret_cast<float*>(smem + WBYTES + C1 * Cfg::RSA);
 
     if constexpr (L1M) {
         // A1 [C1][16 k] bf16 (one 32-byte row per channel), k slots as listed above
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
                 for (int j = 0; j < p.nfeat; ++j) k[j] = p.W1f[(size_t)i * p.ldw1f + j] * iu;
                 k[5] = w.x * iux; k[6] = w.y * iux; k[7] = w.z * iux;
                 if constexpr (F16) {          // (F16 too: layer 1 keeps the two-plane form)
-                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 16;
+                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES + i * Cfg::RSA);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         unsigned o[2];
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
                         d[j] = o[0]; d[4 + j] = o[0]; d[8 + j] = o[1]; d[12 + j] = 0u;
                     }
                 } else if constexpr (NS == 3) {
-                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES) + i * 24;
+                    unsigned* d = reinterpret_cast<unsigned*>(smem + WBYTES + i * Cfg::RSA);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         unsigned o[3];
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[e];
                 }
-                const char* ar = smem + WBYTES + (32 * c + l31) * 96 + half * 16;
+                const char* ar = smem + WBYTES + (32 * c + l31) * Cfg::RSA + half * 16;
                 const u32x4 a0 = *reinterpret_cast<const u32x4*>(ar), a1 = *reinterpret_cast<const u32x4*>(ar + 32), a2 = *reinterpret_cast<const u32x4*>(ar + 64);
                 acc = mfma_planes<3>(a2, b1g, acc);
                 acc = mfma_planes<3>(a1, b1f, acc);
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
             } else if constexpr (L1F) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const char* ar = smem + WBYTES + (32 * c + l31) * 64 + half * 16;
+                const char* ar = smem + WBYTES + (32 * c + l31) * Cfg::RSA + half * 16;
                 const u32x4 ah = *reinterpret_cast<const u32x4*>(ar), al = *reinterpret_cast<const u32x4*>(ar + 32);
                 acc = mfma_planes<2>(al, b1f, acc);
                 return mfma_planes<2>(ah, b1f, acc);

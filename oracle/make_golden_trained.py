@@ -25,6 +25,11 @@ Outputs:
   tests/golden/trained_*.npz            reference-run fixtures on those checkpoints
   profiles/r5_trained_checkpoint_report.txt   what the optimiser did (spreads, dead units, BN statistics, loss curve)
 
+[r6] EV2H_TRAIN_RUN=b: a SECOND, independent run (tests/trained_ckpt.py: RUNS) -- initial weights synth_state_dict(4, 101), torch seed
+2026, other clouds (data seeds 20 000 + step), 1 500 steps (900 with cross entropy x 2 / joint term x 30, then 600 with x 4 / x 5),
+C = 4 only; outputs tests/golden/trained2_weights_c4.npz, trained2_{E,U}_c4_n2048.npz, profiles/r6_trained2_checkpoint_report.txt.
+About two hours on 6 CPU threads.
+
 Run:  python oracle/make_golden_trained.py [train|fixtures|all]      (needs /root/reference; never runs on the GPU box)
 """
 from __future__ import annotations
@@ -46,11 +51,14 @@ from ev2hands_amd import synth  # noqa: E402
 from oracle import make_golden, mano_oracle  # noqa: E402
 import trained_ckpt  # noqa: E402
 
-STEPS = int(os.getenv("EV2H_TRAIN_STEPS", "480"))
-PHASE2 = 320          # from this step on the joint term is weighted 10 instead of 100 and the cross entropy 3 instead of 1
+RUN = os.getenv("EV2H_TRAIN_RUN", "a")
+STEPS = int(os.getenv("EV2H_TRAIN_STEPS", "480" if RUN == "a" else "1500"))
+PHASE2 = 320 if RUN == "a" else 900      # from this step on the joint term is weighted less and the cross entropy more
+LOSS_W = {"a": ((1.0, 100.0), (3.0, 10.0)), "b": ((2.0, 30.0), (4.0, 5.0))}[RUN]          # (w_ce, w_j3d) of the two phases
+TORCH_SEED, DATA_SEED0 = {"a": (2024, 10_000), "b": (2026, 20_000)}[RUN]
 STEPS_C5 = int(os.getenv("EV2H_TRAIN_STEPS_C5", "48"))
 BATCH, POINTS = 4, 2048
-STATE = "/tmp/ev2h_trained_state.pt"
+STATE = "/tmp/ev2h_trained_state.pt" if RUN == "a" else "/tmp/ev2h_trained_state_b.pt"
 MANO_SEED = 0
 CASES = [
     # name,                 kind, C, N,   B, seed
@@ -58,6 +66,9 @@ CASES = [
     ("trained_E_c5_n2048", "E", 5, 2048, 2, 42),
     ("trained_U_c4_n2048", "U", 4, 2048, 2, 43),      # inputs the network never saw: other activation ranges
     ("trained_E_c4_n8192", "E", 4, 8192, 1, 44),
+] if RUN == "a" else [
+    ("trained2_E_c4_n2048", "E", 4, 2048, 2, 45),
+    ("trained2_U_c4_n2048", "U", 4, 2048, 2, 46),
 ]
 
 
@@ -71,7 +82,7 @@ def blob_centres(b: int, seed: int) -> np.ndarray:
 
 
 def make_batch(C: int, step: int):
-    seed = 10_000 + step
+    seed = DATA_SEED0 + step
     xyz = synth.synth_cloud("E", BATCH, C, POINTS, seed)
     labels = torch.zeros(BATCH, POINTS, dtype=torch.long)
     targets = {"left": torch.zeros(BATCH, 22), "right": torch.zeros(BATCH, 22)}
@@ -115,9 +126,9 @@ def loss_fn(out, labels, targets, hands, w_ce=1.0, w_j3d=100.0):
 
 def train_c4(te, hands, log):
     os.environ["ERPC"], os.environ["MHLNES"] = "0", "0"
-    torch.manual_seed(2024)
+    torch.manual_seed(TORCH_SEED)
     net = te.TEHNet(n_pose_params=synth.MANO_CMPS)
-    init = synth.synth_state_dict(4, trained_ckpt.INIT_SEED)
+    init = synth.synth_state_dict(4, trained_ckpt.RUNS[RUN]["init_seed"])
     net.load_state_dict(init, strict=True)
     opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=0.0)          # train.py:22-23,53
     start = 0
@@ -134,7 +145,7 @@ def train_c4(te, hands, log):
         xyz, labels, targets = make_batch(4, step)
         out = net(xyz, hands)                                                     # train.py:83
         # two phases: the joint term (huge at a random start) first, then the segmentation head gets its share of the gradient
-        loss, parts = loss_fn(out, labels, targets, hands, *((1.0, 100.0) if step < PHASE2 else (3.0, 10.0)))
+        loss, parts = loss_fn(out, labels, targets, hands, *(LOSS_W[0] if step < PHASE2 else LOSS_W[1]))
         opt.zero_grad()                                                           # train.py:90-92
         loss.backward()
         opt.step()
@@ -215,7 +226,7 @@ def report(sd, init, log):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.getenv("EV2H_TRAIN_THREADS", "8")))
     pn, te = make_golden.load_reference()
     hands = mano_oracle.make_hands(synth.synth_mano_assets("left", MANO_SEED), synth.synth_mano_assets("right", MANO_SEED))
     lines = []
@@ -227,23 +238,24 @@ def main():
     if what in ("train", "all"):
         sd4, init = train_c4(te, hands, log)
         arrays = trained_ckpt.encode(sd4, init)
-        np.savez_compressed(trained_ckpt.weights_path(4), **arrays)
+        np.savez_compressed(trained_ckpt.weights_path(4, RUN), **arrays)
         sd4q = trained_ckpt.decode(arrays, init)                  # the checkpoint every consumer reconstructs
         drift = max(float((sd4q[k].double() - sd4[k].double()).abs().max()) for k in sd4 if sd4[k].dtype == torch.float32)
-        log(f"wrote {trained_ckpt.weights_path(4)} ({os.path.getsize(trained_ckpt.weights_path(4)) / 2**20:.2f} MiB); "
+        log(f"wrote {trained_ckpt.weights_path(4, RUN)} ({os.path.getsize(trained_ckpt.weights_path(4, RUN)) / 2**20:.2f} MiB); "
             f"fp16-delta rounding moved a weight by at most {drift:.2e}")
-        _sd5, changed = train_c5(te, hands, sd4q, log)
-        np.savez_compressed(trained_ckpt.weights_path(5), **changed)
-        log(f"wrote {trained_ckpt.weights_path(5)} ({os.path.getsize(trained_ckpt.weights_path(5)) / 1024:.1f} KiB)")
+        if RUN == "a":
+            _sd5, changed = train_c5(te, hands, sd4q, log)
+            np.savez_compressed(trained_ckpt.weights_path(5), **changed)
+            log(f"wrote {trained_ckpt.weights_path(5)} ({os.path.getsize(trained_ckpt.weights_path(5)) / 1024:.1f} KiB)")
         report(sd4q, init, log)
-        with open(os.path.join(ROOT, "profiles", "r5_trained_checkpoint_report.txt"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "r5_trained_checkpoint_report.txt" if RUN == "a" else "r6_trained2_checkpoint_report.txt"), "w") as f:
             f.write("\n".join(lines) + "\n")
     if what in ("fixtures", "all"):
         only = sys.argv[2:]
         for name, kind, C, N, B, seed in CASES:
             if only and name not in only:
                 continue
-            sd = trained_ckpt.trained_state_dict(C)
+            sd = trained_ckpt.trained_state_dict(C, RUN)
             make_golden.run_case(pn, te, name, kind, C, N, B, seed, sd_override=sd,
                                  extra={"ckpt": np.array("trained"), "mano_seed": np.array(seed)})
     os.environ["ERPC"], os.environ["MHLNES"] = "0", "0"

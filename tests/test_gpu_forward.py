@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_")))
 # reference-run fixtures on checkpoints that came out of the reference's own training loop (oracle/make_golden_trained.py)
 TRAINED = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "trained_*.npz")) if "weights" not in os.path.basename(p))
+# [r6] ... and of a SECOND, independent training run (other start, seed, clouds, schedule and loss weighting; tests/trained_ckpt.py: RUNS)
+TRAINED += sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "trained2_*.npz")) if "weights" not in os.path.basename(p))
 TOL = 1e-4
 
 
@@ -161,7 +163,7 @@ def test_forward_matches_reference_fixture_on_trained_weights(path, precision):
     this on checkpoints nobody constructed for it."""
     import trained_ckpt
     C = int(np.load(path)["meta"][1])
-    errs = run_reference_fixture(path, precision, sd=trained_ckpt.trained_state_dict(C))
+    errs = run_reference_fixture(path, precision, sd=trained_ckpt.trained_state_dict(C, trained_ckpt.run_of_fixture(path)))
     print(f"trained fixture {os.path.basename(path)} [{precision}]: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
 
 
@@ -173,7 +175,7 @@ def test_bf16_mode_on_trained_weights(path):
     import trained_ckpt
     g = np.load(path)
     B, C, N, seed = [int(v) for v in g["meta"]]
-    net, _sd, _assets = make_net(C, seed, precision="bf16", sd=trained_ckpt.trained_state_dict(C))
+    net, _sd, _assets = make_net(C, seed, precision="bf16", sd=trained_ckpt.trained_state_dict(C, trained_ckpt.run_of_fixture(path)))
     net.net.fps_init = [torch.from_numpy(g["fps_init"][i].astype(np.int64)) for i in range(4)]
     with torch.no_grad():
         out = net(torch.from_numpy(g["xyz"]).cuda())
@@ -216,7 +218,7 @@ def _reduced_mode_metrics(path, precision):
     import trained_ckpt
     g = np.load(path)
     B, C, N, seed = [int(v) for v in g["meta"]]
-    net, _sd, _assets = make_net(C, seed, precision=precision, sd=trained_ckpt.trained_state_dict(C))
+    net, _sd, _assets = make_net(C, seed, precision=precision, sd=trained_ckpt.trained_state_dict(C, trained_ckpt.run_of_fixture(path)))
     net.net.fps_init = [torch.from_numpy(g["fps_init"][i].astype(np.int64)) for i in range(4)]
     with torch.no_grad():
         out = net(torch.from_numpy(g["xyz"]).cuda())

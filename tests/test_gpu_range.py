@@ -340,8 +340,9 @@ def test_hot_pixel_beyond_the_range_of_one_window_is_reported(count, capsys):
     assert report["f16x2"][0] < 5e-2
 
 
+@pytest.mark.parametrize("run", ["a", "b"])
 @pytest.mark.parametrize("transform", ["none", "hidden_1e-3", "hidden_1e5", "channels_2^8", "channels_2^16_dead"])
-def test_trained_checkpoint_under_the_stress_transforms(transform):
+def test_trained_checkpoint_under_the_stress_transforms(transform, run):
     """The function-preserving transforms of this file (hidden activations x alpha, per-channel BatchNorm rescaling with dead units)
     applied ON TOP of the checkpoint that came out of the reference's training loop
     (tests/trained_ckpt.py): the optimiser's own structure (collapsed variances, 2^12 fold-scale spreads, saturated attention)
@@ -356,8 +357,10 @@ def test_trained_checkpoint_under_the_stress_transforms(transform):
     inside 5e-4, and the HEADLINE mode no worse than the two unconditional ones (f16x2 <= 4 x max(f32, bf16x3) + 1e-5)."""
     _need_gpu()
     import trained_ckpt
+    if not trained_ckpt.available(run):
+        pytest.skip(f"training run {run!r} is not committed")
     C, N, B, seed = 4, 1024, 2, 71
-    sd = trained_ckpt.trained_state_dict(C)
+    sd = trained_ckpt.trained_state_dict(C, run)
     xyz = synth.synth_cloud("E", B, C, N, seed)
     if transform.startswith("hidden_"):
         sd = sc.rescale_hidden(sd, float(transform.split("_")[1]))
@@ -382,7 +385,7 @@ def test_trained_checkpoint_under_the_stress_transforms(transform):
         assert torch.isfinite(out["class_logits"]).all()
         errs = check_against(out, net, ref, trace, B, N, tol=5e-4)
         worst[precision] = max(errs.values())
-    print(f"trained checkpoint, {transform}: worst relative error vs the CPU oracle " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
+    print(f"trained checkpoint (run {run}), {transform}: worst relative error vs the CPU oracle " + ", ".join(f"{k} {v:.2e}" for k, v in worst.items()))
     assert worst["f16x2"] <= 4 * max(worst["f32"], worst["bf16x3"]) + 1e-5, worst
 
 

@@ -33,7 +33,7 @@ def test_oracle_matches_reference_fixture(path):
     if "ckpt" in g.files:          # weights that came out of the reference's training loop (oracle/make_golden_trained.py)
         import trained_ckpt
         assert str(g["ckpt"]) == "trained"
-        sd = trained_ckpt.trained_state_dict(C)
+        sd = trained_ckpt.trained_state_dict(C, trained_ckpt.run_of_fixture(path))
     else:
         sd = synth.synth_state_dict(C, seed, n_pose)
     hands = mano_oracle.make_hands(synth.synth_mano_assets("left", seed), synth.synth_mano_assets("right", seed), ncomps=n_pose)

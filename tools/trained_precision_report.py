@@ -26,10 +26,11 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-for C, kind, seed in ((4, "E", 51), (4, "U", 52), (5, "E", 53)):
+CASES = [(4, "E", 51, "a"), (4, "U", 52, "a"), (5, "E", 53, "a")] + ([(4, "E", 54, "b"), (4, "U", 55, "b")] if trained_ckpt.available("b") else [])
+for C, kind, seed, run in CASES:
     os.environ["ERPC"] = "1" if C == 5 else "0"
     assets = {s: synth.synth_mano_assets(s, seed) for s in ("left", "right")}
-    sd = trained_ckpt.trained_state_dict(C)
+    sd = trained_ckpt.trained_state_dict(C, run)
     xyz = synth.synth_cloud(kind, B, C, N, seed).cuda()
     inits = synth.fps_inits(B, N, seed)
     outs = {}
@@ -51,7 +52,7 @@ for C, kind, seed in ((4, "E", 51), (4, "U", 52), (5, "E", 53)):
     top2 = r["logits"].topk(2, dim=1).values
     margin = top2[:, 0] - top2[:, 1]
     scale = float(r["logits"].abs().max())
-    print(f"## trained checkpoint C={C}, {kind}-clouds, B={B}, N={N}: logit scale {scale:.3f}, top-2 margin < 1e-4 scale at "
+    print(f"## trained checkpoint (run {run}) C={C}, {kind}-clouds, B={B}, N={N}: logit scale {scale:.3f}, top-2 margin < 1e-4 scale at "
           f"{float((margin < 1e-4 * scale).float().mean()) * 100:.3f} % of the points, class histogram {torch.bincount(r['logits'].argmax(1).flatten(), minlength=4).tolist()}")
     def rootrel(j):          # [B, 42, 3]: left joints 0..20, right 21..41, each minus its own root (evaluate_ev2hands_r.py:43-54)
         j = j.double().view(j.shape[0], 2, 21, 3)

@@ -16,11 +16,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Clk { unsigned long long core, ref; };
 
 // PATTERN 3: v_mfma_f32_32x32x16_bf16 on the same bit patterns; 4: v_mfma_f32_32x32x2_f32 (the exact-fp32 mode's instruction).
+// PATTERN 5 [r6]: v_mfma_f32_16x16x32_f16 -- the same FLOP per instruction-issue-cycle (16 x 16 x 32 x 2 = 16 384 FLOP in 4 passes against
+//            32 768 in 8) with a QUARTER of the accumulator registers (4 instead of 16 per tile): does the smaller tile hold a higher
+//            clock under the power limit?    Four independent 16 x 16 accumulators, operands as in pattern 0.
 // PATTERN 0: four consecutive MFMAs share the B operand and take different A operands (what the loop nests of the library do: one
 //            activation fragment against several weight fragments); 1: both operands change at every MFMA; 2: both operands fixed.
 template <int WAVES, int PATTERN>
 __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, float* __restrict__ out, Clk* __restrict__ clk, int iters) {
     f32x16 acc[4];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc4[4] = {};
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -41,6 +46,10 @@ __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, 
                 if constexpr (PATTERN == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[u], acc[a], 0, 0, 0);
                 else if constexpr (PATTERN == 1) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[(u + a) & 3], B[(u + 3 * a) & 3], acc[a], 0, 0, 0);
                 else if constexpr (PATTERN == 2) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[0], B[0], acc[a], 0, 0, 0);
+                else if constexpr (PATTERN == 5) {      // two 16 x 16 x 32 MFMAs = the FLOP of one 32 x 32 x 16
+                    acc4[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[(u + a) & 3], B[u], acc4[a], 0, 0, 0);
+                    acc4[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[(u + a + 1) & 3], B[(u + 1) & 3], acc4[a], 0, 0, 0);
+                }
                 else if constexpr (PATTERN == 3) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A[(u + a) & 3]), __builtin_bit_cast(bf16x8, B[u]), acc[a], 0, 0, 0);
                 else acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, (unsigned)(0x3f000000u | (__builtin_bit_cast(unsigned short, A[(u + a) & 3][0]) << 7))),
                                                                    __builtin_bit_cast(float, (unsigned)(0x3f000000u | (__builtin_bit_cast(unsigned short, B[u][1]) << 7))), acc[a], 0, 0, 0);
@@ -49,9 +58,11 @@ __global__ __launch_bounds__(256 * WAVES) void k(const f16x8* __restrict__ ops, 
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[a][r];
+        s += acc4[a][0] + acc4[a][1] + acc4[a][2] + acc4[a][3];
+    }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { clk[blockIdx.x].core = c1 - c0; clk[blockIdx.x].ref = r1 - r0; }
 }
@@ -108,8 +119,11 @@ int main() {
             run<2, 2>("rnd fix", d_ops, ncu);          // the same random operands at every MFMA
             run<2, 3>("rnd bf16", d_ops, ncu);         // v_mfma_f32_32x32x16_bf16, the same bit patterns read as bf16
             run<2, 4>("rnd f32", d_ops, ncu);          // v_mfma_f32_32x32x2_f32, random mantissas in [0.5, 1)
+            run<2, 5>("rnd 16x16", d_ops, ncu);        // v_mfma_f32_16x16x32_f16 (two per 32 x 32 x 16's worth of FLOP), random operands
+            run<1, 5>("rnd 16x16", d_ops, ncu);
         } else {
             run<2, 4>("zero f32", d_ops, ncu);
+            run<2, 5>("zero 16x16", d_ops, ncu);
         }
     }
     return 0;
