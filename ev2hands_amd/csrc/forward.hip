@@ -37,7 +37,7 @@ extern "C" void ev2h_struct_sizes(size_t out[8]) {
     out[7] = sizeof(ev2h_tensor_desc);
 }
 
-static struct SideCtx* side_ctx();
+static struct SideCtx* side_ctx(void* caller_stream = nullptr);
 // per-device, thread-safe, idempotent (common.hpp: PerDevice).  Also creates the calling thread's side stream on the current device
 // NOW: HIP multiplexes streams onto a few hardware queues, and two streams that share one run in order -- a host that is going to
 // create many more streams (torch's stream pool, RCCL's) should call this first, so that the forward's side stream gets a hardware
@@ -94,10 +94,20 @@ struct SideCtx {
     static constexpr int NEV = 14;     // (10 .. 13: the chunks of enc.sa1's sampling)
     hipEvent_t ev[NEV] = {};
     int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
+    void* owner = nullptr;       // the caller's stream this side stream serves (slot 0: the first caller's, claimed at its first forward)
+    bool claimed = false;
 };
 constexpr int EV2H_MAX_DEVICES = 16;
-static thread_local SideCtx g_side[EV2H_MAX_DEVICES];
+// [r6] One side stream PER CALLER STREAM (up to EV2H_SIDE_SLOTS per host thread and device): forwards that are in flight at the same
+// time on different streams (ev2hands_amd/inflight.py, dist.GatherPipeline(inflight=K)) used to share ONE side stream -- harmless
+// while it carried only the tails of a forward, but since enc.sa1's sampling runs there (chunked, ev2h_fps_multi_chunk) forward
+// i + 1's sampling queued behind forward i's right-hand regressor and two forwards in flight bought nothing (16 x 8192: 7 557
+// against 7 568 windows/s with one).  Slot 0 is the stream ev2h_init creates first (it wants a hardware queue of its own).
+constexpr int EV2H_SIDE_SLOTS = 4;
+static thread_local SideCtx g_side[EV2H_MAX_DEVICES][EV2H_SIDE_SLOTS];
 
+static thread_local bool g_side_claim = false;      // set by ev2h_forward / the probe around side_ctx(): this call binds a slot to its caller stream
+static inline bool caller_stream_claims(void*) { return g_side_claim; }
 static thread_local int g_side_disabled = 0;      // ev2h_set_side_stream(0): run everything on the caller's stream (per host thread)
 
 extern "C" int ev2h_set_side_stream(int enabled) {
@@ -106,10 +116,21 @@ extern "C" int ev2h_set_side_stream(int enabled) {
     return prev;
 }
 
-static SideCtx* side_ctx() {     // the current device's side stream, or nullptr (single-stream mode)
+static SideCtx* side_ctx(void* caller_stream) {     // the side stream that serves `caller_stream` on the current device, or nullptr (single-stream mode)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EV2H_MAX_DEVICES) return nullptr;
-    SideCtx& c = g_side[dev];
+    int slot = 0;
+    if (caller_stream || g_side[dev][0].claimed) {
+        // the slot that already serves this caller stream, else the first free one; all taken: share slot 0 (correct, only serialised)
+        int found = -1, free_ = -1;
+        for (int i = 0; i < EV2H_SIDE_SLOTS; ++i) {
+            if (g_side[dev][i].claimed && g_side[dev][i].owner == caller_stream) { found = i; break; }
+            if (!g_side[dev][i].claimed && free_ < 0) free_ = i;
+        }
+        slot = found >= 0 ? found : (free_ >= 0 ? free_ : 0);
+    }
+    SideCtx& c = g_side[dev][slot];
+    if (caller_stream_claims(caller_stream) && !c.claimed) { c.claimed = true; c.owner = caller_stream; }
     if (c.state == 0) {
         const char* e = getenv("EV2H_TWO_STREAMS");
         c.state = -1;
@@ -138,7 +159,9 @@ __global__ void spin_kernel(unsigned long long ticks) {
 extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio) {
     EV2H_CHECK_ARG(ratio && spin_us > 0 && spin_us <= 100000);
     *ratio = 0.f;
-    SideCtx* side = side_ctx();
+    g_side_claim = true;
+    SideCtx* side = side_ctx(stream);
+    g_side_claim = false;
     if (!side || g_side_disabled) {
         ev2h_set_error("ev2h_side_stream_probe: the side stream is switched off");
         return EV2H_ERR_ARG;
@@ -900,7 +923,9 @@ extern "C" int ev2h_forward(const ev2h_weights* w, const ev2h_mano_consts* mano_
         return EV2H_ERR_WORKSPACE;
     }
     const ev2h_mano_consts* mano[2] = {mano_left, mano_right};
-    SideCtx* side = side_ctx();
+    g_side_claim = true;
+    SideCtx* side = side_ctx(st);              // the side stream of THIS caller stream (forwards in flight on other streams have their own)
+    g_side_claim = false;
     if (g_side_disabled) side = nullptr;
     bool forked = false;
     const int rc = forward_body(w, mano, xyz_cm, B, C, N, mhlnes, fps_init, out, ws, st, side, &forked);
