@@ -46,6 +46,15 @@ __device__ __forceinline__ f32x16 mfma_planes(u32x4 a, u32x4 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// the 16 x 16 x 32 form: D[16 x 16] += A[16 x 32] * B[32 x 16]; lane l holds A[i = l & 15][k = 8 (l >> 4) ..+8], B[k = 8 (l >> 4) ..+8][j = l & 15],
+// D[i = 4 (l >> 4) + r][j = l & 15], r = 0..3.  Same FLOP per issue cycle as the 32 x 32 x 16 form with a quarter of the accumulator
+// registers -- and 17-18 % more sustained throughput at the power limit (profiles/r6_mfma_ceiling.txt).
+template <int NS>
+__device__ __forceinline__ f32x4 mfma16_planes(u32x4 a, u32x4 b, f32x4 c) {
+    if constexpr (planes_f16(NS)) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float relu_bits(float x) {     // max(x, 0) as one integer max: no canonicalisation op, -0 -> +0
     const int i = __builtin_bit_cast(int, x);
     return __builtin_bit_cast(float, i > 0 ? i : 0);

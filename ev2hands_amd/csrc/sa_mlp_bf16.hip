@@ -256,6 +256,26 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
 #endif
     using Cfg = SaBCfg<C1, C2, C3, NS>;
     using PL = Planes<NS>;
+    // L3T16 [r6]: LAYER 3 ON v_mfma_f32_16x16x32 (planes.hpp: mfma16_planes).  A pure stream of that instruction sustains 0.73-0.77 of the
+    // 2.5 PFLOP/s peak on random operands where the 32 x 32 x 16 form sustains 0.62-0.65 (same FLOP per cycle, a quarter of the
+    // accumulator traffic: the power limit sets the clock, profiles/r6_mfma_ceiling.txt), and layer 3 is 62 % of this kernel's MFMA work.
+    // Layers 1-2 keep the 32 x 32 form and its D layout (lane = neighbour j, registers = channels); the A operand of a 16 x 16 x 32 MFMA
+    // wants lane group G = l >> 4 to hold k-group G of neighbour l & 15, which is a regrouping of 16-lane rows between the two k-block
+    // registers of a tile: P = h2p[.][t][0] = rows [P0 P1 P2 P3], Q = h2p[.][t][1]; v_permlane32_swap then v_permlane16_swap (gfx950,
+    // one VALU op each; tools/ubench/permlane_swap_check.hip) give [P0 P2 Q0 Q2] = neighbours 0..15 x k-groups 0..3 and [P1 P3 Q1 Q3]
+    // = neighbours 16..31.  The W3 images are read as they are (16-row fragments: row l & 15, 16 bytes at k offset 32 t + 8 G).
+    // Same products, same plane order; the sums associate differently (32 k per MFMA, two neighbour tiles), so results agree with
+    // the 32 x 32 form to fp32 rounding, not bit for bit (all 100 set-abstraction operator tests pass with it).
+    // MEASURED AND NOT ADOPTED (profiles/r6_ab_l3t16_refuted.txt): the kernels are no faster (kbench: 1.653 / 1.807 / 1.747 ms against
+    // 1.638 / 1.835 / 1.756 for the three 128-196-256 shapes) and the whole step is 1.6 % (f16x2) / 2.0 % (f16) SLOWER, same box,
+    // builds interleaved -- the pure-stream advantage of the smaller tile does not survive the kernel's own mix (112 more VALU ops
+    // per strip for the regrouping, twice the MFMA issue slots).  Opt-in for whoever re-tiles layers 1-2 as well (then the
+    // regrouping disappears): EV2H_BUILD_DEFS=-DEV2H_L3T16.
+#ifdef EV2H_L3T16
+    constexpr bool L3T16 = !ROWS && (NS == 2 || NS == 4) && (RES || Cfg::UPT == 2);
+#else
+    constexpr bool L3T16 = false;
+#endif
     constexpr int NPL = Cfg::NPL;
     constexpr bool F16 = Cfg::F16;
     constexpr int T2 = Cfg::T2, T3 = Cfg::T3, NC1 = Cfg::NC1, RS2 = Cfg::RS2, RS3 = Cfg::RS3, C2P = Cfg::C2P;
@@ -379,6 +399,9 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
     // index of this group in the caller's arrays (centroids, index lists, counts, output rows)
     const size_t gf = ROWS ? (size_t)gg : (size_t)b * p.S_total + p.s_off + (gg - b * p.S);
     float mrun[T3];
+    float m16[L3T16 ? T3 : 1][2];          // L3T16: running maxima per 16-channel half of an output tile (this lane's column l & 15)
+#pragma unroll
+    for (int u = 0; u < (L3T16 ? T3 : 1); ++u) m16[u][0] = m16[u][1] = -INFINITY;
 #pragma unroll
     for (int u = 0; u < T3; ++u) mrun[u] = -INFINITY;
 
@@ -953,8 +976,23 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
         // H2FUSE: only tile 0 is split here; tile t + 1 is split between the MFMA groups of tile t in the FIRST layer-3 step, so that
         // the conversion (VALU) of one wave runs under the MFMAs of its SIMD partner instead of both waves converting while the matrix
         // pipe idles (phase timeline: "h2 ReLU + split" was 8 % of a strip).  Same values, same order of the contraction.
+        // L3T16: regroup the 16-lane rows of tile t's two k-block registers into the A operands of the two neighbour tiles
+        auto perm16 = [&](int t) {
+            if constexpr (L3T16) {
 #pragma unroll
-        for (int t = 0; t < (H2FUSE ? 1 : T2); ++t) { split_half(t, 0); split_half(t, 1); }
+                for (int s = 0; s < NPL; ++s)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+                        const u32x2_ a = __builtin_amdgcn_permlane32_swap(h2p[s][t][0][w], h2p[s][t][1][w], false, false);
+                        const u32x2_ b_ = __builtin_amdgcn_permlane16_swap(a[0], a[1], false, false);
+                        h2p[s][t][0][w] = b_[0];          // neighbours 0..15, k-groups 0..3 of tile t
+                        h2p[s][t][1][w] = b_[1];          // neighbours 16..31
+                    }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < (H2FUSE ? 1 : T2); ++t) { split_half(t, 0); split_half(t, 1); perm16(t); }
         STAMP(39);
 
         // ---------------- layer 3 + max: D3[neighbour][channel] = H2 (A, registers) x W3 tile (B, LDS, permuted k order)
@@ -986,6 +1024,69 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
             }
             float b3u = 0.f;
             if constexpr (ROWS) b3u = p.b3[32 * u + l31];      // (requested here, used after the step's MFMAs)
+            if constexpr (L3T16) {
+                // two output tiles (u, u + 1) x two neighbour tiles x two 16-channel halves: eight 16 x 16 accumulators (32 registers,
+                // as the two 32 x 32 ones); groups (t, c): one B fragment per plane and output tile feeds both neighbour tiles
+                f32x4 a16[2][2][2];          // [output tile][neighbour tile][channel half]
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a16[i >> 2][(i >> 1) & 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int lg = lane >> 4, l15 = lane & 15;
+                const char* pb16 = cur + l15 * RS3;
+                constexpr int NG16 = 2 * T2;
+                auto ld16 = [&](int g, u32x4 (&x)[2][NPL]) {
+                    const int t = g >> 1, c = g & 1;
+                    // the last tile of a width that fills only its first k-block (M_LAST == 1): k-groups 2, 3 do not exist in the image
+                    // (their A values are exact zeros: padded channels) -- read k-groups 0, 1 again instead of whatever follows the row
+                    const int kg = (t == T2 - 1 && Cfg::M_LAST == 1) ? (lg & 1) : lg;
+#pragma unroll
+                    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                        for (int s = 0; s < NPL; ++s)
+                            x[uu][s] = *reinterpret_cast<const u32x4*>(pb16 + uu * Cfg::TB3 + (16 * c) * RS3 + s * (C2P * 2) + (32 * t + 8 * kg) * 2);
+                };
+                u32x4 fw16[2][2][NPL];
+                if constexpr (FRAG_PIPE) ld16(0, fw16[0]);
+#pragma unroll
+                for (int g = 0; g < NG16; ++g) {
+                    const int t = g >> 1, c = g & 1;
+                    if constexpr (FRAG_PIPE) {
+                        if (g + 1 < NG16) ld16(g + 1, fw16[(g + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        ld16(g, fw16[g & 1]);
+                    }
+                    u32x4 (&w)[2][NPL] = fw16[g & 1];
+#pragma unroll
+                    for (int j = 0; j < PL::NPROD; ++j) {
+                        if (Cfg::PACK4 && t == T2 - 1 && !(PL::A[j] == 0 && PL::B[j] == 0)) continue;   // one MFMA holds all three products
+#pragma unroll
+                        for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                            for (int nu = 0; nu < 2; ++nu)
+                                a16[uu][nu][c] = mfma16_planes<NS>(h2p[PL::A[j]][t][nu], w[uu][PL::B[j]], a16[uu][nu][c]);
+                    }
+                    if constexpr (FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (FIRST) {
+                        if (t + 1 < T2) {
+                            if constexpr (!FRAG_PIPE) __builtin_amdgcn_sched_barrier(0);
+                            split_half(t + 1, c);                      // tile t + 1 is converted between the groups of tile t ...
+                            if (c == 1) perm16(t + 1);                 // ... and regrouped once both of its k-blocks exist
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                STAMP(41 + 4 * u);
+                // max over this lane's 8 rows (2 neighbour tiles x 4 registers) per (output tile, channel half)
+#pragma unroll
+                for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x4 x = a16[uu][0][c], y = a16[uu][1][c];
+                        const float mx = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])));
+#pragma unroll
+                        for (int q = 0; q < T3; ++q) m16[q][c] = (q == u + uu) ? fmaxf(m16[q][c], mx) : m16[q][c];
+                    }
+            } else {
             f32x16 acc, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
@@ -1078,6 +1179,7 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
                     finish_tile(u, acc);
                 }
             }
+            }       // (!L3T16)
             STAMP(42 + 4 * u);
             if constexpr (!RES) {
                 if ((u + TPS - 1) % UPT == UPT - 1) {
@@ -1092,6 +1194,17 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
 #pragma unroll 1
         for (int u = H2FUSE ? TPS : 0; u < T3; u += TPS) l3_step(u, std::false_type{});
         STAMP(37);
+    }
+    if constexpr (L3T16) {
+        // the maxima over the lane groups (rows 4 G + r of both neighbour tiles), then this lane's channel 32 u + (l & 31): its half is
+        // (l >> 4) & 1 -- from here on the epilogue is the 32 x 32 form's (every lane group holds the same reduced values)
+#pragma unroll
+        for (int u = 0; u < T3; ++u) {
+            float v0 = m16[u][0], v1 = m16[u][1];
+            v0 = fmaxf(v0, __shfl_xor(v0, 16, 64)); v1 = fmaxf(v1, __shfl_xor(v1, 16, 64));
+            v0 = fmaxf(v0, __shfl_xor(v0, 32, 64)); v1 = fmaxf(v1, __shfl_xor(v1, 32, 64));
+            mrun[u] = ((lane >> 4) & 1) ? v1 : v0;
+        }
     }
 
     if constexpr (!ROWS && !RES) {
