@@ -396,8 +396,12 @@ static int dense(const ev2h_dense& w, const float* X, int ldx, int M, float* Y, 
 // one multi-scale set abstraction given its selections: layer-1 table GEMM + one fused kernel per radius.
 // Range records (F16X2): feat_amax / feat_amax2 = records of the table's input rows, p1_amax / p1_scale = record and storage scale
 // of the table, out_amax = record of the module's output.
+// chain: the table is read by the fused SET-ABSTRACTION kernels (not by a row chain).  F16 [r6]: those keep one power of two per window
+// for the whole chain, so the table's storage scale s must also keep H2' = (s / u2) H2 below 2^15 for every branch:
+//   bound' = max(B1, max_br (|W2|_1 B1 + max|b2|) / u2)  <=  [alpha max(1, max_br |W2|_1 / u2)] max|X| + max(beta, max_br (|W2|_1 beta + max|b2|) / u2)
+// with B1 = alpha max|X| + beta the layer-1 bound of the other modes (ev2h_sa_desc.p1_scale, F16 contract).
 static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, int ldf, int B, int Npts, float* P1, ev2h_stream_t st,
-                    const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale) {
+                    const uint32_t* feat_amax, uint32_t* p1_amax, float* p1_scale, bool chain = true) {
     int c1sum = 0;
     float extra = 0.f;                   // max over the branches of |W1x|_1 * radius: what layer 1 adds to a table entry
     for (int i = 0; i < m.nbranch; ++i) {
@@ -414,6 +418,15 @@ static int sa_table(int precision, const ev2h_sa_module& m, const float* feat, i
         g.x_amax = feat_amax; g.x_group_rows = Npts;
         g.y_amax = p1_amax; g.y_group_rows = Npts;
         g.y_scale = p1_scale; g.y_bound_w = m.w1f_norm; g.y_bound_b = m.b1_max + extra;
+        if (precision == EV2H_PREC_F16 && chain) {
+            float wmul = 1.f, badd = g.y_bound_b;
+            for (int i = 0; i < m.nbranch; ++i) {
+                const float iu = 1.000001f / (m.br[i].w2_unscale > 0.f ? m.br[i].w2_unscale : 1.f);
+                wmul = fmaxf(wmul, m.br[i].w2_norm * iu);
+                badd = fmaxf(badd, (m.br[i].w2_norm * g.y_bound_b + m.br[i].b2_max) * iu);
+            }
+            g.y_bound_w *= wmul; g.y_bound_b = badd;
+        }
     }
     return ev2h_gemm(&g, st);
 }
@@ -780,7 +793,7 @@ static int forward_body(const ev2h_weights* w, const ev2h_mano_consts* const* ma
         // the two hidden layers (3 x 268 MB written and read back at B = 256) never reach memory
         const ev2h_sa_module& m = w->fp1m;
         if (fork) EV2H_CHECK_HIP(hipStreamWaitEvent((hipStream_t)st, side->ev[9], 0));      // 3-NN selection: fork 1 above
-        RUN(sa_table(prec_rows, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4)));
+        RUN(sa_table(prec_rows, m, ws.f("l1new"), 128, B, 512, ws.f("fp1T"), st, ws.r(R_L1NEW), ws.r(R_FP1T), ws.p1scale(4), false));
         ev2h_fp_desc d{};
         d.T = ws.f("fp1T"); d.ldt = 128; d.nn_idx = ws.i("nn1_idx"); d.nn_w = ws.f("nn1_w");
         d.b2 = m.br[0].b2; d.b3 = m.br[0].b3; d.W2s = m.br[0].W2s; d.W3s = m.br[0].W3s;

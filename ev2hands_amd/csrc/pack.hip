@@ -391,6 +391,23 @@ double plane_unscale(const double* W, size_t count, int ns) {
     return std::ldexp(1.0, -k);
 }
 
+// F16 (one fp16 plane) [r6]: the factor of a chain's SECOND matrix.  The fused set-abstraction kernels keep ONE power of two per window
+// for the whole chain in this mode (layer 2's accumulators are converted as they are: no factor between the layers, csrc/sa_mlp_bf16.hip
+// C2ONE), so H2' = (s1 / u2) H2 must land in the fp16 range next to H1' = s1 H1: u2 = 2^floor(log2 |W2|_1) (largest row L1 norm) makes
+// the two bounds agree to a factor of 2-4.  One plane has no low part to protect: a weight 2^-14 below the row norm is still normal.
+double chain_unscale(const double* W, int rows, int cols) {
+    double m = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        double a = 0.0;
+        for (int k = 0; k < cols; ++k) a += std::fabs(W[(size_t)r * cols + k]);
+        if (a > m || a != a) m = a;
+    }
+    if (m == 0.0 || !std::isfinite(m)) return 1.0;
+    int ex;
+    (void)std::frexp(m, &ex);                               // m = f * 2^ex, f in [0.5, 1): floor(log2 m) = ex - 1
+    return std::ldexp(1.0, std::max(-60, std::min(ex - 1, 24)));
+}
+
 void sa_geometry(int C2, int* T2, int* C2P) {
     *T2 = up(C2, 32) / 32;
     const int rem = C2 % 32, m_last = rem == 0 ? 2 : (rem <= 16 ? 1 : 2);
@@ -402,7 +419,7 @@ struct SaImages { std::vector<uint8_t> i2, i3; float u2 = 1.f, u3 = 1.f; };
 // Byte images of the LDS weight tiles of sa_mlp_max_bf16_kernel (SaBCfg in csrc/sa_mlp_bf16.hip).  W2 [C2][C1], W3 [C3][C2].
 SaImages sa_images(const double* W2in, const double* W3in, int C1, int C2, int C3, int ns) {
     SaImages R;
-    const double u2 = plane_unscale(W2in, (size_t)C2 * C1, ns), u3 = plane_unscale(W3in, (size_t)C3 * C2, ns);
+    const double u2 = ns == 4 ? chain_unscale(W2in, C2, C1) : plane_unscale(W2in, (size_t)C2 * C1, ns), u3 = plane_unscale(W3in, (size_t)C3 * C2, ns);
     R.u2 = (float)u2; R.u3 = (float)u3;
     int T2, C2P;
     sa_geometry(C2, &T2, &C2P);
@@ -613,7 +630,7 @@ struct Builder {
         SaImages im = sa_images(W2, W3, C1, C2, C3, ns);
         br.w2_unscale = im.u2; br.w3_unscale = im.u3;
         if (is_f16(ns)) {
-            P.wspread.push_back(weight_spread(n + ".W2", W2, (size_t)C2 * C1, im.u2));
+            P.wspread.push_back(weight_spread(n + ".W2", W2, (size_t)C2 * C1, plane_unscale(W2, (size_t)C2 * C1, ns)));      // (F16: u2 is the chain's factor, the spread is still counted against the largest weight)
             P.wspread.push_back(weight_spread(n + ".W3", W3, (size_t)C3 * C2, im.u3));
         }
         dev_bytes(&br.W2s, n + ".W2s", im.i2);

@@ -413,7 +413,23 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
     // f16x2 range: with P1' = s1 P1 (table stored scaled) and d' = s1 d the layer-1 output is H1' = s1 H1 <= a1 + s1 |W1x|_1 dmax
     // (< 2^15 by the table's choice of s1); layer 2 accumulates (s1 / u2)(W2 H1 + b2); H2' = s2 H2 with the power of two s2 that
     // keeps the bound |W2|_1 max(H1) + max|b2| below 2^15; layer 3 accumulates (s2 / u3) W3 H2.  All factors are exact.
-    float s1 = 1.f, c2 = p.u2, c3 = p.u3;
+    // [r6] F16 set abstractions (one fp16 plane): ONE power of two per window for the whole chain.  s1 is chosen (here for raw feature rows,
+    // by the table's producer otherwise) so that H1' = s1 H1 AND H2' = (s1 / u2) H2 -- layer 2's accumulators as they are -- stay below
+    // 2^15; with u2 = 2^floor(log2 |W2|_1) (pack.hip: chain_unscale) the two bounds agree to a factor 2-4, and one plane loses nothing to a
+    // few binades of headroom.  The conversion of H2 is then cvt + packed ReLU + packed clamp, without the two multiplies by c2
+    // (whole step +6.7 % in a timing build, profiles/r6_f16_chain_scale.txt).  The row chains (ROWS) read rows whose scale
+    // their producer chose for the rows alone: they keep the factor.
+#ifdef EV2H_F16_CLAMP
+    constexpr bool F16_CLAMP = true;              // EV2H_BUILD_DEFS=-DEV2H_F16_CLAMP: clamp the fp16 conversions of the F16 mode at 65504 (A/B)
+#else
+    constexpr bool F16_CLAMP = false;
+#endif
+#ifdef EV2H_F16_NO_C2ONE
+    constexpr bool C2ONE = false;                 // EV2H_BUILD_DEFS=-DEV2H_F16_NO_C2ONE: a factor per layer as in f16x2 (A/B)
+#else
+    constexpr bool C2ONE = NS == 4 && !ROWS;
+#endif
+    float s1 = 1.f, c2 = p.u2, c3 = C2ONE ? p.u3 * p.u2 : p.u3;      // (without range arguments: s1 = 1; C2ONE: H2' = H2 / u2 as accumulated)
     float so = 1.f;                                             // F16 row chain with fp16 output rows: their per-window power of two
     float b1s_f = 1.f, b1s_x = 1.f, b1s_b = 1.f;               // F16 L1M: the B operand's factors s1 a1f, s1 a1x, s1 a1b (wave-uniform)
     const bool fform = fmode || (L1M && hasfeat);               // layer 1 reads raw feature rows (no table, no producer that chose s1)
@@ -422,7 +438,8 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
             // no table and no producer that chose s1: the same bound, evaluated here from the record of the feature rows
             const float bnd = __fmaf_rn(p.w1f_norm, __uint_as_float(p.feat_amax[b]), p.b1_max) + p.w1x_norm * p.dmax;
             s1 = f16x2_scale(__float_as_uint(bnd));
-            const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bnd, p.b2_max)));
+            float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bnd, p.b2_max)));
+            if constexpr (C2ONE) { s1 = fminf(s1, p.u2 * s2); s2 = s1 * pow2_inverse(p.u2); }     // one power of two for the chain: c2 = 1
             c2 = p.u2 * s2 * pow2_inverse(s1);
             c3 = p.u3 * pow2_inverse(s2);
         } else if (!fform && p.p1_amax) {
@@ -434,9 +451,16 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
             else s1 = p.p1_scale[b];
             const float inv_s1 = pow2_inverse(s1);
             const float bh1 = a1 + s1 * (p.w1x_norm * p.dmax);
-            const float s2 = f16x2_scale(__float_as_uint(__fmaf_rn(p.w2_norm, bh1 * inv_s1, p.b2_max)));
+            const float bh2 = __fmaf_rn(p.w2_norm, bh1 * inv_s1, p.b2_max);
+            float s2 = f16x2_scale(__float_as_uint(bh2));
             c2 = p.u2 * s2 * inv_s1;
             c3 = p.u3 * pow2_inverse(s2);
+            if constexpr (C2ONE) {
+                // the table's producer chose s1 for the whole chain (ev2h_sa_desc.p1_scale, F16 contract): H2' = (s1 / u2) H2 as accumulated.
+                // A scale that breaks the contract would saturate hidden values silently: the window's output is NaN instead.
+                s2 = s1 * pow2_inverse(p.u2);
+                c3 = (s2 * bh2 <= 65504.f) ? p.u3 * pow2_inverse(s2) : __uint_as_float(0x7fc00000u);
+            }
         }
         // wave-uniform by construction (one group per wave): keep the three factors in scalar registers
         s1 = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s1)));
@@ -720,13 +744,13 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
         auto finish_slice = [&](int c, int j4, u32x4 (&bp)[2][NPL]) {
             if constexpr (L1M) {
                 // ReLU on the packed bf16 / fp16 pairs: one v_pk_max_i16 per pair (negative floats are negative int16 patterns in both
-                // formats).  F16: D1 is s1 H1 already (the factors rode on the operands); + one v_pk_min_i16 that clamps an overflowed
-                // conversion (+inf = 0x7c00) to the largest fp16 -- what relu_sat_f16 does for the two-plane mode
+                // formats).  F16: D1 is s1 H1 already (the factors rode on the operands).  No clamp of an overflowed conversion (the
+                // two-plane mode's relu_sat_f16 is free, here it would be a v_pk_min_i16 per pair): see F16_CLAMP
 #pragma unroll
                 for (int w = 2 * j4; w < 2 * j4 + 2; ++w) {
                     unsigned o[1];
                     split_planes<NS>(d1[2 * w], d1[2 * w + 1], o);
-                    bp[w >> 2][0][w & 3] = F16 ? sat_pk_f16(relu_pk_bf16(o[0])) : relu_pk_bf16(o[0]);
+                    bp[w >> 2][0][w & 3] = (F16 && F16_CLAMP) ? sat_pk_f16(relu_pk_bf16(o[0])) : relu_pk_bf16(o[0]);
                 }
             } else if (fmode) {
                 if constexpr (L1F && NS == 3) {
@@ -953,7 +977,14 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
 #pragma unroll
             for (int k = 4 * m; k < 4 * m + 4; ++k) {
                 unsigned o[NPL];
-                if constexpr (F16) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
+                if constexpr (C2ONE) {      // (c2 = 1)
+                    // cvt + one packed integer max, as in BF16.  No clamp: the bound behind s1 is rigorous, and a caller who breaks the
+                    // contract behind it (dmax) gets inf -> NaN outputs instead of silently clamped ones.  (Same-box A/B, whole step,
+                    // profiles/r6_f16_chain_scale.txt: a factor per layer 40 630, chain scale 41 200, without the clamps 41 740 windows/s.)
+                    split_planes<NS>(h2[t][2 * k], h2[t][2 * k + 1], o);
+                    o[0] = F16_CLAMP ? sat_pk_f16(relu_pk_bf16(o[0])) : relu_pk_bf16(o[0]);
+                }
+                else if constexpr (F16) split_planes<NS>(relu_sat_f16(h2[t][2 * k] * c2), relu_sat_f16(h2[t][2 * k + 1] * c2), o);
                 else if constexpr (NS == 1) { split_planes<NS>(h2[t][2 * k], h2[t][2 * k + 1], o); o[0] = relu_pk_bf16(o[0]); }     // (u2 = 1: no factor)
                 else split_planes<NS>(relu_bits(h2[t][2 * k] * c2), relu_bits(h2[t][2 * k + 1] * c2), o);
 #pragma unroll
@@ -1232,7 +1263,8 @@ __global__ __launch_bounds__(SAB_THREADS, (sab_min_waves<C1, C2, C3, NS, RES, MO
         for (int u = 0; u < T3; ++u) {
             const float v = fmaxf(mrun[u], __shfl_xor(mrun[u], 32, 64));
             if (valid && half == 0 && sw == 0) {
-                const float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
+                float o = fmaxf(v * c3 + p.b3[32 * u + l31], 0.f);
+                if constexpr (C2ONE) o = (c3 == c3) ? o : c3;          // (fmaxf drops a NaN: the broken-contract marker must reach the caller)
                 p.out[gf * p.ldo + 32 * u + l31] = o;
                 am = max(am, __float_as_uint(o));
             }

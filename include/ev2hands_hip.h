@@ -221,12 +221,17 @@ typedef struct ev2h_sa_desc {
     /* F16X2 activation range (optional; see "Range records").  The layer-1 table arrives scaled: P1 holds s[b] * (W1f' f + b1')
      * with the power of two p1_scale[b] = s[b] chosen by the table's producer (ev2h_gemm y_scale) such that
      * s[b] * (max|P1_b| + w1x_norm * dmax) < 2^15, and p1_amax[b] = max|stored P1_b|.  The hidden activations of layers 1 and 2
-     * are then kept inside the fp16 range by exact per-window powers of two derived from these bounds. */
+     * are then kept inside the fp16 range by exact per-window powers of two derived from these bounds.
+     * EV2H_PREC_F16 [r6]: ONE power of two per window serves the whole chain (layer 2's accumulators are converted without a factor
+     * of their own), so the producer's s[b] must ALSO satisfy (s[b] / w2_unscale) * (w2_norm * B1 + b2_max) < 2^15 with
+     * B1 = max|P1_b| / s[b] + w1x_norm * dmax (ev2h_pack_sa_images chooses w2_unscale = 2^floor(log2 w2_norm) in this mode, so the two
+     * conditions agree to a factor 2-4).  A window whose scale breaks this gets NaN outputs, not saturated ones. */
     const float* p1_scale;       /* [B]; NULL = P1 unscaled, no range handling                                          */
     const uint32_t* p1_amax;     /* [B]                                                                                 */
     float w1x_norm;              /* max_c (|W1x[c][0]| + |W1x[c][1]| + |W1x[c][2]|)                                     */
     float dmax;                  /* contract: every grouped neighbour lies within dmax of its centroid per coordinate
-                                    (the ball-query radius); hidden values are saturated at 65504 if it is broken        */
+                                    (the ball-query radius); if it is broken, hidden values are saturated at 65504
+                                    (F16X2) or overflow to inf and the outputs to NaN (F16: no clamp, one VALU op per pair)  */
     float w2_norm;               /* max row L1 norm of W2                                                               */
     float b2_max;                /* max |b2|                                                                            */
     uint32_t* out_amax;          /* [B] range record of `out` (atomicMax), optional                                     */

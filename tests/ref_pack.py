@@ -131,6 +131,16 @@ def plane_unscale(W: np.ndarray, ns: int) -> float:
     return float(2.0 ** -k)
 
 
+def chain_unscale(W2: np.ndarray) -> float:
+    """f16 (one fp16 plane): the factor of a chain's second matrix, 2^floor(log2 of the largest row L1 norm) -- the fused
+    set-abstraction kernels keep one power of two per window for the whole chain in that mode (csrc/pack.hip: chain_unscale)."""
+    import math
+    m = float(np.abs(np.asarray(W2, dtype=np.float64)).sum(axis=1).max()) if np.size(W2) else 0.0
+    if m == 0.0 or not np.isfinite(m):
+        return 1.0
+    return float(2.0 ** max(-60, min(math.frexp(m)[1] - 1, 24)))
+
+
 def sa_bf16_geometry(C2: int):
     T2 = _up(C2, 32) // 32
     rem = C2 % 32
@@ -150,7 +160,7 @@ def sa_bf16_images(W2: np.ndarray, W3: np.ndarray, ns: int):
     """Byte images of the LDS weight tiles of sa_mlp_max_bf16_kernel (see SaBCfg in csrc/sa_mlp_bf16.hip).
     W2 [C2, C1], W3 [C3, C2] folded fp32 weights.  Returns (W2s, W3s, u2, u3): uint8 images of W2 / u2 and W3 / u3 and the
     power-of-two factors (plane_unscale) the kernel multiplies back."""
-    u2, u3 = plane_unscale(W2, ns), plane_unscale(W3, ns)
+    u2, u3 = (chain_unscale(W2) if ns == 4 else plane_unscale(W2, ns)), plane_unscale(W3, ns)
     W2 = np.asarray(W2, dtype=np.float64) / u2
     W3 = np.asarray(W3, dtype=np.float64) / u3
     C2, C1 = W2.shape

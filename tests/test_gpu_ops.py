@@ -323,6 +323,10 @@ def test_sa_mlp_max_table_form_with_range_records(mag, precision, tol):
     W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = W1x
     dmax = float(dxyz.abs().max()) * 1.0001
     bound = P1.abs().amax((1, 2)) + float(W1x.abs().sum(1).max()) * dmax            # what the table's producer bounds layer 1 by
+    if precision == "f16":           # one power of two for the whole chain (ev2h_sa_desc.p1_scale, F16 contract): also (s / u2)(|W2|_1 B1 + max|b2|) < 2^15
+        l1 = float(W2.abs().sum(1).max())
+        u2 = 2.0 ** np.floor(np.log2(l1))
+        bound = torch.maximum(bound, (l1 * 1.000001 * bound + float(b2.abs().max())) / u2)
     sc_ = torch.exp2(torch.floor(torch.log2(32768.0 / bound)))
     sc_ = torch.where(sc_ * bound >= 32768.0, sc_ / 2, sc_)
     P1s = (P1 * sc_.view(B, 1, 1)).contiguous()                                    # exact: powers of two
@@ -335,6 +339,35 @@ def test_sa_mlp_max_table_form_with_range_records(mag, precision, tol):
     print(f"table form with range records, {precision}, layer-1 magnitude {mag:g}: rel err {err:.2e}")
     assert torch.isfinite(got).all() and err < tol
     assert torch.equal(ops.range_values(out_amax).cpu(), got.abs().amax(dim=(1, 2)).cpu())
+
+
+def test_f16_table_scale_that_breaks_the_chain_contract_is_loud():
+    """[r6] In `f16` the table's storage scale serves the whole chain (include/ev2hands_hip.h, ev2h_sa_desc.p1_scale).  A producer that
+    bounds layer 1 only -- fine for f16x2 -- with a second layer whose bias pushes H2 far above H1: the kernel must not saturate
+    silently; the affected windows come back NaN."""
+    _need_gpu()
+    from ev2hands_amd import ops
+    C1, C2, C3, K, B, Npts, S = 64, 64, 128, 64, 2, 256, 8
+    g = lambda n, s, sc=1.0: torch.from_numpy(synth.hash_normal(n, s, 79) * sc).float()
+    P1 = g("P1", (B, Npts, C1))
+    xyz = cloud_xyz("U", B, Npts, 46)
+    ctr = xyz[:, :S].contiguous()
+    gidx = torch.from_numpy(synth.hash_randint("gi", 0, Npts, (B, S, K), 80)).int()
+    W1x4 = torch.zeros(C1, 4); W1x4[:, :3] = g("W1x", (C1, 3), 0.5)
+    W2, b2 = g("W2", (C2, C1), C1 ** -0.5), g("b2", (C2,), 1e4)              # H2 ~ 1e4 next to H1 ~ 1
+    W3, b3 = g("W3", (C3, C2), C2 ** -0.5), g("b3", (C3,), 0.1)
+    bi = torch.arange(B).view(B, 1, 1)
+    dmax = float((xyz[bi, gidx.long()] - ctr.view(B, S, 1, 3)).abs().max()) * 1.0001
+    bound = P1.abs().amax((1, 2)) + float(W1x4.abs().sum(1).max()) * dmax     # layer 1 only
+    sc_ = torch.exp2(torch.floor(torch.log2(32768.0 / bound)))
+    sc_ = torch.where(sc_ * bound >= 32768.0, sc_ / 2, sc_)
+    P1s = (P1 * sc_.view(B, 1, 1)).contiguous()
+    p1_amax = ops.range_record(B, "cuda")
+    p1_amax.view(torch.float32).copy_(P1s.abs().amax((1, 2)))
+    run = lambda precision: ops.sa_mlp_max(P1s.cuda(), ops.pack_points(xyz.cuda()), ops.pack_points(ctr.cuda()), gidx.cuda(), W1x4.cuda(), W2.cuda(), b2.cuda(),
+                                           W3.cuda(), b3.cuda(), C2, precision, p1_scale=sc_.cuda(), p1_amax=p1_amax, dmax=dmax)
+    assert torch.isfinite(run("f16x2")).all()             # every layer has its own power of two there
+    assert torch.isnan(run("f16")).all()
 
 
 SA_CASES = [(32, 32, 64, 32), (64, 64, 128, 64), (64, 96, 128, 128), (128, 128, 256, 64), (128, 196, 256, 128)]
