@@ -51,7 +51,9 @@ def main():
     worst = 0.0
     trained = bool(os.environ.get("FUZZ_TRAINED"))
     tol = 2e-4 if trained else 2e-5
+    F16_TOL = float(os.environ.get("FUZZ_F16_TOL", "0.2" if trained else "0.05"))
     all_worst = []
+    f16_worst = []
     if trained:
         import trained_ckpt
     for case in range(ncases):
@@ -70,9 +72,14 @@ def main():
         seed = int(rng.integers(0, 10 ** 6))
         variant = str(rng.choice(["plain", "channels", "dead", "heavy", "hidden"]))
         p1, p2 = float(rng.random()), float(rng.random())         # drawn for every case, so that FUZZ_ONLY replays a case exactly
+        p3, bigb = float(rng.random()), int(rng.integers(8, 25))  # [r6] a quarter of the cases at 8..24 windows: enc.sa1's sampling in four
+        if p3 < 0.25 and N <= 4096 and not os.environ.get("FUZZ_SMALL"):      # launches on the side stream (forward.hip: chunked), resident
+            B = bigb if N <= 2048 else min(bigb, 10)                          # kernels whose waves straddle windows
         if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != case:
             continue
-        sd = trained_ckpt.trained_state_dict(C) if trained else synth.synth_state_dict(C, seed)
+        # (trained: the second optimiser run's checkpoint [r6] for every other C = 4 case)
+        trun = "b" if (trained and C == 4 and case % 2 == 1 and trained_ckpt.available("b")) else "a"
+        sd = trained_ckpt.trained_state_dict(C, trun) if trained else synth.synth_state_dict(C, seed)
         if trained and variant == "heavy":
             variant = "plain"                                # (re-drawing the weights' magnitudes would un-train them)
         if variant == "channels":
@@ -130,9 +137,31 @@ def main():
                 o = tehnet_oracle.tehnet_forward(sd, xyz.cpu().clone(), hands, fps_init=inits, mhlnes=bool(mh))
             truth = {"class_logits": o["class_logits"], **{f"{s_}.{k}": o[s_][k] for s_ in ("left", "right") for k in KEYS}}
             print("   f32 mode vs fp32 CPU oracle:", {k: f"{rel(ref[k], truth[k]):.1e}" for k in ref})
-        modes = ["f16x2"] + (["bf16x3"] if case % 3 == 0 else [])
+        modes = ["f16x2"] + (["bf16x3"] if case % 3 == 0 else []) + (["f16"] if case % 2 == 0 else [])
         case_worst = 0.0
         for prec in modes:
+            if prec == "f16":
+                # [r6] the one-plane mode: 11 bits per operand -- no 2e-5 bar.  Required: identical selections, finite, deterministic,
+                # every float output within F16_TOL of the exact-fp32 mode (2^-11 times the network's conditioning: 1e-3 .. 1e-2 on these
+                # checkpoints), argmax agreement >= 99 % of the points; the distribution is printed with the summary.
+                got, gsel = run(net, xyz, inits, prec)
+                again, _ = run(net, xyz, inits, prec)
+                for n in SEL:
+                    if not torch.equal(gsel[n], rsel[n]):
+                        msgs.append(f"f16: selection {n} differs")
+                errs = {k: rel(got[k], ref[k]) for k in ref}
+                agree = float((ref["class_logits"].argmax(1) == got["class_logits"].argmax(1)).float().mean())
+                f16_worst.append((max(errs.values()), agree))
+                if max(errs.values()) > F16_TOL:
+                    k = max(errs, key=errs.get)
+                    msgs.append(f"f16: {k} rel err {errs[k]:.2e}")
+                if agree < 0.99:
+                    msgs.append(f"f16: argmax agreement {agree:.4f}")
+                if any(not torch.equal(got[k], again[k]) for k in got):
+                    msgs.append("f16: not deterministic")
+                if any(not torch.isfinite(v).all() for v in got.values()):
+                    msgs.append("f16: non-finite output")
+                continue
             got, gsel = run(net, xyz, inits, prec)
             again, _ = run(net, xyz, inits, prec)
             for n in SEL:
@@ -157,7 +186,7 @@ def main():
                 msgs.append(f"{prec}: not deterministic")
             if any(not torch.isfinite(v).all() for v in got.values()):
                 msgs.append(f"{prec}: non-finite output")
-        print(f"case {case:3d}: C={C} {kind} B={B} N={N:5d} mhlnes={mh} ckpt={variant:22s} seed={seed:6d}  {case_worst:.1e}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
+        print(f"case {case:3d}: C={C} {kind} B={B} N={N:5d} mhlnes={mh} ckpt={variant + ('/run-b' if trun == 'b' else ''):22s} seed={seed:6d}  {case_worst:.1e}  {'OK' if not msgs else 'FAIL ' + '; '.join(msgs)}", flush=True)
         bad += bool(msgs)
         all_worst.append(case_worst)
         del net
@@ -165,6 +194,11 @@ def main():
     if all_worst:
         q = np.quantile(np.array(all_worst), [0.5, 0.9, 0.99])
         print(f"per-case worst difference: median {q[0]:.1e}, 90th percentile {q[1]:.1e}, 99th {q[2]:.1e}" + ("  (trained checkpoints)" if trained else ""))
+    if f16_worst:
+        e = np.array([x[0] for x in f16_worst]); g = np.array([x[1] for x in f16_worst])
+        q = np.quantile(e, [0.5, 0.9, 1.0])
+        print(f"f16 (one fp16 plane), {len(e)} cases: worst float difference median {q[0]:.1e}, 90th percentile {q[1]:.1e}, max {q[2]:.1e}; "
+              f"argmax agreement min {g.min():.5f}, median {np.median(g):.5f}")
     return 1 if bad else 0
 
 
