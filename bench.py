@@ -111,6 +111,11 @@ def parse(argv=None):
                          "parity assets, whose vertices and faces are independent random draws (every mesh intersects itself ~24 000 times: "
                          "the worst case for the pair search)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--shared-device", action="store_true",
+                    help="REHEARSAL of an N-rank run on a box with ONE GPU: every rank runs the real forward on device 0, the process group is "
+                         "gloo (RCCL refuses two ranks on one device) and the gather goes through dist.py's host-staged transport.  Everything "
+                         "but RCCL's transport runs as in the real run -- launcher, sharding, barriers, max-over-ranks, per-rank fields, the "
+                         "line's key set; the line is marked \"rehearsal\" and its throughput (N processes time-slicing one GPU) means nothing")
     ap.add_argument("--stub", action="store_true",
                     help="CPU self-test of the multi-rank plumbing (launcher, gloo all-gather, max-over-ranks timing) with fabricated "
                          "predictions; prints a line marked \"stub\": true that is not a measurement")
@@ -456,6 +461,8 @@ def run_rank(a) -> int:
     if a.stub:
         dev = torch.device("cpu")
     else:
+        if a.shared_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if not a.stub:
@@ -472,7 +479,7 @@ def run_rank(a) -> int:
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if a.stub:
+        if a.stub or a.shared_device:
             dist.init_process_group("gloo")
         else:
             import datetime
@@ -568,6 +575,8 @@ def run_rank(a) -> int:
         pending = pipe.submit()
         return pending.result() if sync_gather else pending
 
+    cdev = torch.device("cpu") if a.shared_device else dev        # where the scalar collectives' tensors live (gloo: host)
+
     def sync():
         if not a.stub and infl is not None:
             infl.drain()
@@ -587,7 +596,7 @@ def run_rank(a) -> int:
                 hook()
         sync()
         dt_ = time.perf_counter() - t0
-        tmax = torch.tensor([dt_], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt_], device=cdev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         timed.local = dt_
@@ -595,10 +604,10 @@ def run_rank(a) -> int:
 
     def all_ranks(value):
         """[value of rank 0, ..., value of rank world-1] on every rank"""
-        t = torch.tensor([float(value)], device=dev, dtype=torch.float64)
+        t = torch.tensor([float(value)], device=cdev, dtype=torch.float64)
         if not use_dist:
             return [float(t.item())]
-        full = torch.zeros(world_seen, device=dev, dtype=torch.float64)
+        full = torch.zeros(world_seen, device=cdev, dtype=torch.float64)
         dist.all_gather_into_tensor(full, t)
         return [float(v) for v in full.tolist()]
 
@@ -692,7 +701,11 @@ def run_rank(a) -> int:
                     dist.barrier()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                dist.all_gather_into_tensor(b0.full, b0.full[lo_:lo_ + b0.big])
+                if b0.host_staged:                         # (--shared-device: gloo, the buffer's pinned-host transport)
+                    b0._gather(async_op=False)
+                    b0._landed()
+                else:
+                    dist.all_gather_into_tensor(b0.full, b0.full[lo_:lo_ + b0.big])
                 e1.record()
                 torch.cuda.synchronize()
                 gms.append(e0.elapsed_time(e1))
@@ -812,10 +825,13 @@ def run_rank(a) -> int:
                                        else "random triangle soup (every mesh intersects itself ~24 000 times: worst case for the pair search)")
                                       if a.collision else ""),
                        "global_batch": gB, "points": N, "channels": Cc, "precision": a.precision, "forwards_in_flight": a.inflight,
-                       "world_size_seen": world_seen, "backend": ("gloo" if a.stub else "nccl (RCCL)") if use_dist else None,
+                       "world_size_seen": world_seen, "backend": ("gloo" if (a.stub or a.shared_device) else "nccl (RCCL)") if use_dist else None,
                        "parallelism": f"batch-shard x{world}" + ((" + in-place RCCL all-gather of predictions (the forward writes into the gather buffer; " +
                                                                        ("in stream order)" if sync_gather else "asynchronous, overlapped with the next forward)")) if use_dist else "")},
         }
+        if a.shared_device:
+            res["rehearsal"] = (f"{world} ranks time-slicing ONE GPU under a gloo process group (host-staged gather): the launcher, sharding, barriers, "
+                                "max-over-ranks timing and every per-rank field run as in the real run, RCCL's transport does not; `value` is not a measurement")
         if a.stub:
             res["stub"] = True
             res["would_emit"] = expected_line_keys(world, a)      # what the real path prints at this world size (tests/test_bench_launcher.py)

@@ -104,7 +104,7 @@ class Outputs(C.Structure):
 
 
 EXPORTS = [
-    "ev2h_abi_version", "ev2h_source_hash", "ev2h_build_defs", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_side_stream_probe", "ev2h_shader_clock_probe", "ev2h_struct_sizes",
+    "ev2h_abi_version", "ev2h_source_hash", "ev2h_build_defs", "ev2h_last_error", "ev2h_init", "ev2h_set_side_stream", "ev2h_side_stream_probe", "ev2h_streams_concurrent", "ev2h_bind_stream", "ev2h_shader_clock_probe", "ev2h_struct_sizes",
     "ev2h_prep_points", "ev2h_fps", "ev2h_fps_multi", "ev2h_ball_query", "ev2h_three_nn_interp",
     "ev2h_gemm", "ev2h_transpose_logits", "ev2h_sa_mlp_max", "ev2h_fp_mlp", "ev2h_tile_geometry",
     "ev2h_attn_sim", "ev2h_attn_sim_folded", "ev2h_attn_sim_folded_scratch", "ev2h_attn_context", "ev2h_mano", "ev2h_mano_rotations",
@@ -160,6 +160,8 @@ def lib() -> C.CDLL:
     L.ev2h_set_side_stream.argtypes = [ci]
     L.ev2h_side_stream_probe.argtypes = [vp, ci, C.POINTER(C.c_float)]
     L.ev2h_shader_clock_probe.argtypes = [vp, ci, vp]
+    L.ev2h_streams_concurrent.argtypes = [vp, vp, ci, C.POINTER(C.c_float)]
+    L.ev2h_bind_stream.argtypes = [vp, C.POINTER(ci)]
     L.ev2h_prep_points.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
     L.ev2h_fps_multi.argtypes = [vp, ci, ci, ci, C.POINTER(ci), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp]
@@ -246,6 +248,44 @@ def side_stream_probe(spin_us: int = 50) -> float:
     r = C.c_float(0.0)
     check(lib().ev2h_side_stream_probe(stream_handle(), int(spin_us), C.byref(r)), "ev2h_side_stream_probe")
     return float(r.value)
+
+
+def streams_concurrent(a: int, b: int, spin_us: int = 40) -> float:
+    """ev2h_streams_concurrent on two raw stream handles of the current device: ~1.0-1.3 concurrent, ~2 = one hardware queue"""
+    r = C.c_float(0.0)
+    check(lib().ev2h_streams_concurrent(a, b, int(spin_us), C.byref(r)), "ev2h_streams_concurrent")
+    return float(r.value)
+
+
+def bind_stream(handle: int | None = None) -> tuple:
+    """ev2h_bind_stream for a raw stream handle (default: the current stream): (candidates tried, ratio of the chosen pair, earlier-bound
+    streams still sharing a queue with it); (0, 0.0, 0) when there was nothing to do (bound before, capturing, single-stream mode)."""
+    info = (ci * 3)()
+    check(lib().ev2h_bind_stream(stream_handle() if handle is None else handle, info), "ev2h_bind_stream")
+    return int(info[0]), info[1] / 1000.0, int(info[2])
+
+
+def concurrent_streams(device, n: int, pool: int = 8) -> list:
+    """n torch streams of `device` that the device runs CONCURRENTLY with each other, as far as the hardware queues allow: torch hands
+    out streams of a pool round robin and HIP maps them onto a few hardware queues, so two fresh streams may well share one and then
+    run in order.  Greedy: keep a candidate if it is concurrent with every stream kept so far; if the pool is exhausted first, the
+    rest are taken as they come (correct, only serialised)."""
+    import torch
+    device = torch.device(device)
+    with torch.cuda.device(device):
+        cands = [torch.cuda.Stream(device) for _ in range(max(pool, n))]
+        kept = []
+        for c in cands:
+            if len(kept) == n:
+                break
+            if all(streams_concurrent(k.cuda_stream, c.cuda_stream) < 1.6 for k in kept):
+                kept.append(c)
+        for c in cands:
+            if len(kept) == n:
+                break
+            if all(c is not k for k in kept):
+                kept.append(c)
+    return kept
 
 
 class ShaderClockSampler:

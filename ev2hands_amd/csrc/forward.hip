@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "common.hpp"
 #include "planes.hpp"
@@ -38,6 +39,7 @@ extern "C" void ev2h_struct_sizes(size_t out[8]) {
 }
 
 static struct SideCtx* side_ctx(void* caller_stream = nullptr);
+static void side_open(struct SideCtx& c);
 // per-device, thread-safe, idempotent (common.hpp: PerDevice).  Also creates the calling thread's side stream on the current device
 // NOW: HIP multiplexes streams onto a few hardware queues, and two streams that share one run in order -- a host that is going to
 // create many more streams (torch's stream pool, RCCL's) should call this first, so that the forward's side stream gets a hardware
@@ -96,6 +98,7 @@ struct SideCtx {
     int state = 0;               // 0 = not tried, 1 = ready, -1 = disabled
     void* owner = nullptr;       // the caller's stream this side stream serves (slot 0: the first caller's, claimed at its first forward)
     bool claimed = false;
+    bool bound = false;          // ev2h_bind_stream has measured this pair (and replaced the stream if it shared the caller's hardware queue)
 };
 constexpr int EV2H_MAX_DEVICES = 16;
 // [r6] One side stream PER CALLER STREAM (up to EV2H_SIDE_SLOTS per host thread and device): forwards that are in flight at the same
@@ -131,6 +134,11 @@ static SideCtx* side_ctx(void* caller_stream) {     // the side stream that serv
     }
     SideCtx& c = g_side[dev][slot];
     if (caller_stream_claims(caller_stream) && !c.claimed) { c.claimed = true; c.owner = caller_stream; }
+    side_open(c);
+    return c.state == 1 ? &c : nullptr;
+}
+
+static void side_open(SideCtx& c) {
     if (c.state == 0) {
         const char* e = getenv("EV2H_TWO_STREAMS");
         c.state = -1;
@@ -144,7 +152,6 @@ static SideCtx* side_ctx(void* caller_stream) {     // the side stream that serv
             if (ok) c.state = 1;
         }
     }
-    return c.state == 1 ? &c : nullptr;
 }
 
 // ---------------------------------------------------------------------------------------- side-stream probe
@@ -155,6 +162,116 @@ __global__ void spin_kernel(unsigned long long ticks) {
     while (wall_clock64() - r0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 }  // namespace
+
+namespace {
+// (time of one spin kernel on each of a and b at once) / (time of one on a alone): ~1.0-1.3 = concurrent, ~2 = the streams share a hardware queue
+hipError_t probe_pair(hipStream_t a, hipStream_t b, int spin_us, float* ratio) {
+    *ratio = 0.f;
+    hipEvent_t e[6] = {};
+    hipError_t err = hipSuccess;
+    for (auto& x : e) if (err == hipSuccess) err = hipEventCreate(&x);
+    int rate_khz = 100000, dev = 0;                         // wall_clock64 ticks per millisecond
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    const unsigned long long ticks = (unsigned long long)rate_khz * (unsigned long long)spin_us / 1000ull;
+    float one = 0.f, two = 0.f;
+    for (int rep = 0; rep < 2 && err == hipSuccess; ++rep) {   // (first repetition: code load, queue wake-up)
+        err = hipEventRecord(e[0], a);
+        spin_kernel<<<1, 64, 0, a>>>(ticks);
+        if (err == hipSuccess) err = hipEventRecord(e[1], a);
+        if (err == hipSuccess) err = hipEventRecord(e[4], a);                   // fork exactly as ev2h_forward does
+        if (err == hipSuccess) err = hipStreamWaitEvent(b, e[4], 0);
+        if (err == hipSuccess) err = hipEventRecord(e[2], a);
+        spin_kernel<<<1, 64, 0, a>>>(ticks);
+        spin_kernel<<<1, 64, 0, b>>>(ticks);
+        if (err == hipSuccess) err = hipEventRecord(e[5], b);
+        if (err == hipSuccess) err = hipStreamWaitEvent(a, e[5], 0);
+        if (err == hipSuccess) err = hipEventRecord(e[3], a);
+        if (err == hipSuccess) err = hipStreamSynchronize(a);
+    }
+    if (err == hipSuccess) err = hipEventElapsedTime(&one, e[0], e[1]);
+    if (err == hipSuccess) err = hipEventElapsedTime(&two, e[2], e[3]);
+    for (auto& x : e) if (x) (void)hipEventDestroy(x);
+    if (err == hipSuccess) *ratio = one > 0.f ? two / one : 0.f;
+    return err;
+}
+constexpr float SERIALISED = 1.6f;          // concurrent pairs measure 1.0-1.3 (the second launch's latency), serialised ones 1.9-2.1
+}  // namespace
+
+extern "C" int ev2h_streams_concurrent(ev2h_stream_t a, ev2h_stream_t b, int spin_us, float* ratio) {
+    EV2H_CHECK_ARG(ratio && spin_us > 0 && spin_us <= 100000);
+    const hipError_t err = probe_pair((hipStream_t)a, (hipStream_t)b, spin_us, ratio);
+    if (err != hipSuccess) { ev2h_set_error("ev2h_streams_concurrent: %s", hipGetErrorString(err)); return EV2H_ERR_HIP; }
+    return EV2H_OK;
+}
+
+// [r6] HIP multiplexes a process's streams onto a few hardware queues (4 by default) and two streams that share one run IN ORDER, without
+// any error.  Which queue a stream gets depends on what the process created before it (torch's pool of 32, RCCL's streams, other
+// libraries): with the library's side stream created first and one forward at a time the default mapping works (ev2h_init), but
+// with forwards in flight on several caller streams -- each with a side stream of its own -- no creation order is right for every
+// host (measured in the 1-rank RCCL process, 16 x 8192, profiles/r6_side_slots_ab.txt: every slot created at ev2h_init: two in flight
+// 9 010 windows/s but ONE in flight 5 980 instead of 7 400 and B = 256 -4 %; slots created at first use: one in flight 7 400, two
+// 7 350 instead of 9 000).  So the mapping is MEASURED: ev2h_bind_stream probes candidate side streams against the caller's stream and
+// against the streams this thread has bound before, and keeps the one that really runs beside them.
+extern "C" int ev2h_bind_stream(ev2h_stream_t stream, int* info) {
+    if (info) info[0] = info[1] = info[2] = 0;
+    if (g_side_disabled) return EV2H_OK;
+    int dev = 0;
+    EV2H_CHECK_HIP(hipGetDevice(&dev));
+    EV2H_CHECK_ARG(dev >= 0 && dev < EV2H_MAX_DEVICES);
+    g_side_claim = true;
+    SideCtx* side = side_ctx(stream);
+    g_side_claim = false;
+    if (!side) return EV2H_OK;                                  // single-stream mode: nothing to bind
+    if (!(side->claimed && side->owner == stream)) return EV2H_OK;   // every slot taken: this stream shares slot 0 (serialised with its owner's tails, correct)
+    if (side->bound) return EV2H_OK;                            // measured before: the cheap path of a call per forward
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return EV2H_OK;      // the probe synchronises: not now (stays unbound)
+    // the streams bound before on this thread and device: a good side stream also stays out of THEIR way
+    std::vector<hipStream_t> others;
+    for (int i = 0; i < EV2H_SIDE_SLOTS; ++i) {
+        SideCtx& o = g_side[dev][i];
+        if (&o == side || !o.claimed || o.state != 1) continue;
+        others.push_back((hipStream_t)o.owner);
+        others.push_back(o.stream);
+    }
+    constexpr int SPIN_US = 40;
+    hipError_t err = hipSuccess;
+    auto score = [&](hipStream_t cand, float* own_ratio) {      // 100 if serialised with its own caller stream, + 1 per other stream it is serialised with
+        int sc = 0;
+        float r = 0.f;
+        if (err == hipSuccess) err = probe_pair(st, cand, SPIN_US, &r);
+        *own_ratio = r;
+        if (r > SERIALISED) sc += 100;
+        for (hipStream_t o : others) {
+            float ro = 0.f;
+            if (err == hipSuccess) err = probe_pair(o, cand, SPIN_US, &ro);
+            if (ro > SERIALISED) ++sc;
+        }
+        return sc;
+    };
+    float best_ratio = 0.f;
+    int best = score(side->stream, &best_ratio), tried = 1;
+    std::vector<hipStream_t> rejected;
+    while (err == hipSuccess && best > 0 && tried < 8) {
+        hipStream_t cand = nullptr;
+        if (hipStreamCreateWithFlags(&cand, hipStreamNonBlocking) != hipSuccess) break;
+        ++tried;
+        float r = 0.f;
+        const int sc = score(cand, &r);
+        if (err == hipSuccess && sc < best) { rejected.push_back(side->stream); side->stream = cand; best = sc; best_ratio = r; }
+        else rejected.push_back(cand);
+    }
+    // (destroyed only now: a destroyed stream's queue slot would be handed to the next candidate)
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    if (err != hipSuccess) { ev2h_set_error("ev2h_bind_stream: %s", hipGetErrorString(err)); return EV2H_ERR_HIP; }
+    side->bound = true;
+    // (best > 0: more streams in flight than hardware queues -- two forwards and their side streams fill the default four.  Running
+    //  such a caller stream WITHOUT a side stream was measured and is worse: 16 x 8192, three in flight, 8 470 against 9 030 windows/s.)
+    if (info) { info[0] = tried; info[1] = (int)(best_ratio * 1000.f + 0.5f); info[2] = best % 100; }
+    return EV2H_OK;
+}
 
 extern "C" int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio) {
     EV2H_CHECK_ARG(ratio && spin_us > 0 && spin_us <= 100000);

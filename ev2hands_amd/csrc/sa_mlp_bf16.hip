@@ -9,6 +9,8 @@
 //           machinery (range records, per-window powers of two, W / u planes); layer 1 is BF16's matrix-pipe form (L1M: ONE
 //           MFMA per chunk, inputs as two fp16 planes, weights as one) under wave-uniform powers of two.  NS = 4 is a mode code:
 //           plane_count(NS) = 1 planes are stored, planes_f16(NS) selects the fp16 MFMA and the range scaling (planes.hpp).
+//           The set abstractions keep ONE power of two per window for the whole chain in this mode (C2ONE in the kernel): layer 2's
+//           accumulators are converted as they are, as in BF16.
 // All biases, ReLUs and the max stay in fp32.  Layer 1 has three forms (see L1M / L1F / the VALU path in the kernel):
 //   * gathered layer-1 table row + exact fp32 relative-xyz fma chain (every mode when the features are a real table: enc.sa2);
 //   * BF16: one MFMA per 32-channel chunk (inputs as two bf16 planes), on top of the table row or -- raw feature rows -- instead of it;

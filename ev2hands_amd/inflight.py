@@ -33,9 +33,9 @@ class InflightForward:
     current stream first (the input is ready) and for the slot's previous forward by stream order.  `rows=` as in TEHNet.forward
     (the multi-GPU gather buffer; `dist.GatherPipeline(..., inflight=K)` composes the two).
 
-    One host thread at a time: every slot's forward forks onto the library's ONE side stream (per host thread and device) and joins
-    it with the library's events, which is correct for interleaved forwards only when their enqueue calls do not interleave --
-    submit() holds a lock for the duration of the enqueue."""
+    One host thread at a time: every slot's forward forks onto the side stream the library keeps for that slot's stream (per host
+    thread and device; up to four, beyond that slot 0's is shared) and joins it with that slot's events; the library's tables are
+    per host thread, so submit() holds a lock for the duration of the enqueue."""
 
     class Ticket:
         def __init__(self, out, event, device):
@@ -62,8 +62,13 @@ class InflightForward:
         if self.streams is None:
             with torch.cuda.device(device):             # the library's side stream first, ON THIS DEVICE (it wants a hardware queue of its own)
                 _lib.check(_lib.lib().ev2h_init(), "ev2h_init")
-            self.streams = [torch.cuda.Stream(device) for _ in range(self.depth)]
+            # [r6] slot streams that the device really runs side by side, each with a side stream that runs beside all of them: HIP
+            # maps streams onto a few hardware queues and two that share one run in order -- measured, not assumed
+            # (_lib.concurrent_streams, ev2h_bind_stream; what comes out depends on what else the process created: profiles/r6_side_slots_ab.txt)
+            self.streams = _lib.concurrent_streams(device, self.depth)
             self.device = torch.device(device)
+            with torch.cuda.device(device):
+                self.binding = [_lib.bind_stream(s_.cuda_stream) for s_ in self.streams]
         elif torch.device(device) != self.device:
             raise RuntimeError(f"InflightForward was started on {self.device}, got a batch on {device}")
         k = self.i % self.depth

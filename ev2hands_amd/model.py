@@ -273,6 +273,9 @@ class TEHNet(nn.Module):
         elif ws.numel() < nbytes or ws.device != device:
             raise RuntimeError("workspace too small or on another device")
         with torch.cuda.device(device):
+            # [r6] the side stream of THIS caller stream is chosen by measurement the first time (ev2h_bind_stream: a stream that shares
+            # the caller's hardware queue would silently serialise the forward's overlaps); afterwards the call returns at once
+            _lib.check(L.ev2h_bind_stream(_lib.stream_handle(), None), "ev2h_bind_stream")
             _lib.check(L.ev2h_forward(C.byref(pw.struct), consts["left"], consts["right"], x.data_ptr(), B, Cin, N, self.mhlnes,
                                       init_dev.data_ptr(), C.byref(out), ws.data_ptr(), nbytes, _lib.stream_handle()),
                        "ev2h_forward")

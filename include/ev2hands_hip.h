@@ -104,6 +104,20 @@ int ev2h_set_side_stream(int enabled);
  * `stream` (a start-up probe, ~0.2 ms); not capturable.  Returns EV2H_ERR_ARG when the side stream is switched off
  * (EV2H_TWO_STREAMS=0 / creation failed): then there is nothing to probe and *ratio is set to 0.  [ABI 7] */
 int ev2h_side_stream_probe(ev2h_stream_t stream, int spin_us, float* ratio);
+/* [ABI 8] Do two streams of this process run concurrently on the current device?  One spin kernel on `a` alone, then one on each of
+ * `a` and `b` at once (b forked from a by an event, as ev2h_forward forks): *ratio = pair / one, ~1.0-1.3 concurrent, ~2 = the two
+ * share a hardware queue and run in order.  Synchronises `a`; not capturable. */
+int ev2h_streams_concurrent(ev2h_stream_t a, ev2h_stream_t b, int spin_us, float* ratio);
+/* [ABI 8] Bind a side stream to `stream` that the device REALLY runs beside it (optional; once per caller stream, before or between
+ * forwards -- ev2hands_amd calls it ahead of every forward, after the first time it returns at once).  The hardware queue a HIP
+ * stream lands on depends on everything the process created before it (a framework's stream pool, RCCL, other libraries), so no
+ * creation order is right for every host -- least of all with forwards in flight on several caller streams, each with a side
+ * stream of its own.  This call MEASURES: it probes the slot's side stream against `stream` and against every stream the calling
+ * thread has bound before (ev2h_streams_concurrent), and while a pair is serialised creates another candidate (at most 8) and keeps
+ * the best; rejected candidates are destroyed.  Synchronises `stream` (~1-5 ms, once); does nothing while `stream` is capturing,
+ * in single-stream mode, or when all side-stream slots (4 per host thread and device) serve other streams.
+ * info (optional, int[3]): candidates tried, 1000 x ratio of the chosen pair, number of earlier-bound streams it still shares a queue with. */
+int ev2h_bind_stream(ev2h_stream_t stream, int* info);
 /* [ABI 8] What shader clock is the chip running at RIGHT NOW?  Enqueues a one-wave kernel on `stream` that sleeps for ~spin_us
  * microseconds and writes out_dev[0] = elapsed shader-clock cycles (s_memtime), out_dev[1] = elapsed ticks of the constant 100 MHz
  * reference counter (s_memrealtime): clock in MHz = 100 * out_dev[0] / out_dev[1].  The matrix-pipe kernels are power-limited on

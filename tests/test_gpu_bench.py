@@ -114,3 +114,29 @@ def test_bench_line_carries_the_cpu_baseline_on_the_multi_gpu_path():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert j["line_complete"] is True and j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
+
+
+@pytest.mark.parametrize("world,inflight", [(2, 1), (4, 2)])
+def test_multi_rank_rehearsal_on_one_gpu_prints_a_complete_line(world, inflight):
+    """[r6] `bench.py --gpus N --shared-device`: the launcher starts N real ranks that all run the HIP forward on device 0 under a gloo
+    process group (RCCL refuses two ranks on one device; the gather goes through dist.py's host-staged transport).  Everything the
+    first real N-GPU run will execute except RCCL's transport: sharding of the global FPS starts, barriers, max-over-ranks timing,
+    per-rank step times / shader clocks / side-stream probes, the CPU leg on rank 0 after the last barrier, the key set."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--shared-device", "--steps", "5", "--warmup", "1", "--batch", "8",
+           "--inflight", str(inflight), "--no-legs", "--no-latency", "--no-traffic", "--no-host-io", "--no-second-site", "--sustained-seconds", "0.3",
+           "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-1000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == world and j["config"]["world_size_seen"] == world and j["config"]["backend"] == "gloo" and "rehearsal" in j
+    assert j["line_complete"] is True, j["line_complete"]
+    assert j["config"]["global_batch"] == 8 * world and j["config"]["forwards_in_flight"] == inflight
+    assert len(j["ms_per_step_per_rank"]["all"]) == world and all(v > 0 for v in j["ms_per_step_per_rank"]["all"])
+    assert abs(j["value"] - 8 * world * 1e3 / j["ms_per_step"]) <= 0.01 * j["value"]
+    assert len(j["value_sustained"]["shader_clock_mhz_median_per_rank"]) == world
+    sc = j["multi_gpu_selfcheck"]
+    assert len(sc["two_stream_gain_per_rank"]) == world and len(sc["gather_ms_per_rank"]) == world, sc
+    assert j["cpu_baseline"]["value"] > 0 and j["roofline"]["traffic_kind"] in ("committed", "live")

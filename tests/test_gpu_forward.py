@@ -837,6 +837,36 @@ def test_bf16_table_switch_agrees_with_the_table_free_layer1(tmp_path):
     assert worst < 3e-2 and agree > 0.97
 
 
+@pytest.mark.parametrize("name,value,bit_identical", AB_SWITCHES, ids=[n for n, _, _ in AB_SWITCHES])
+def test_ab_switch_paths_in_f16(tmp_path, name, value, bit_identical):
+    """[r6] The same switches under `f16` (one fp16 plane): the alternative paths -- layer-1 tables whose producer chooses the chain's
+    power of two (EV2H_L1_TABLE), streamed weights, one stream, chunked sampling at 3 windows, the un-fused row chains, l0 as fp32 --
+    must give the same selections and outputs within the mode's own rounding (bit-identical where the arithmetic is the same)."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = tmp_path / "run.py"
+    script.write_text(_AB_SCRIPT.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).replace("('f16x2', 'bf16x3')", "('f16',)"))
+    env0 = {k: v for k, v in os.environ.items() if k not in {n for n, _, _ in AB_SWITCHES}}
+    res = {}
+    for tag, env in (("default", {}), ("alt", {name: value})):
+        out = tmp_path / f"{tag}.pt"
+        r = subprocess.run([sys.executable, str(script), str(out)], env=dict(env0, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)["f16"]
+    for k in ("gidx", "nn"):
+        assert torch.equal(res["default"][k], res["alt"][k]), k
+    floats = [k for k in res["default"] if k not in ("gidx", "nn")]
+    assert all(torch.isfinite(res["alt"][k]).all() for k in floats)
+    worst = max(rel(res["default"][k], res["alt"][k]) for k in floats)
+    agree = float((res["default"]["logits"].argmax(1) == res["alt"]["logits"].argmax(1)).float().mean())
+    print(f"f16, {name}={value}: worst relative difference to the default path {worst:.2e}, argmax agreement {agree:.5f}")
+    if bit_identical and name != "EV2H_L0_F32":
+        assert worst == 0.0
+    else:
+        assert worst < 1e-2 and agree > 0.995
+
+
 def test_query_convolution_without_q1_agrees_with_the_two_pass_form(tmp_path):
     """[r4, bf16x3: r5] bf16 / f16x2 / bf16x3 at window sizes that tile by 128 rows: the first query convolution forms the attention's key-weighted sums in its
     epilogue and never writes q1 (gemm_bf16.hip: zsum_epilogue).  EV2H_ATTN_UNFUSED_ZSUM=1 = q1 to memory + attn_zsum_kernel (the

@@ -3,6 +3,8 @@ operand tensors (ev2h_range_report), TEHNet.verify_precision (f16x2 against bf16
 and a stress checkpoint whose hidden activations are large in a way no weight norm shows (coherent rows on correlated,
 non-negative inputs with stale BatchNorm statistics).  The fp32 semantics being guarded: pointnet2_utils.py:253-256,312-314,
 TEHNet.py:135-166 (every layer is fp32 in the reference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -227,13 +229,66 @@ def test_side_stream_probe_sees_two_concurrent_streams():
     net, sd, assets = make_net(4, 1, precision="f16x2")          # creates the side stream (ev2h_init)
     r = [_lib.side_stream_probe(50) for _ in range(3)]
     print("side-stream probe (pair / single):", [f"{v:.2f}" for v in r])
-    assert 0.8 < min(r) < 1.5, r
+    assert 0.6 < min(r) < 1.5, r          # (~2 = one hardware queue; a ratio below 1 is the single spin's own launch jitter)
     prev = _lib.lib().ev2h_set_side_stream(0)
     try:
         with pytest.raises(_lib.Ev2hError):
             _lib.side_stream_probe(50)
     finally:
         _lib.lib().ev2h_set_side_stream(prev)
+
+
+_HOSTILE_HOST = """
+import sys, torch
+sys.path.insert(0, {root!r})
+torch.cuda.set_device(0)
+# a host that has created (and used) dozens of streams before the library is even loaded: torch's pool and then some
+pool = [torch.cuda.Stream() for _ in range(48)]
+x = torch.zeros(64, device='cuda')
+for s in pool:
+    with torch.cuda.stream(s):
+        x.add_(1)
+torch.cuda.synchronize()
+from ev2hands_amd import _lib, synth
+from ev2hands_amd.inflight import InflightForward
+from ev2hands_amd.model import TEHNetWrapper
+assets = {{s: synth.synth_mano_assets(s, 0) for s in ('left', 'right')}}
+net = TEHNetWrapper('cuda:0', mano_assets=assets, precision='f16x2')
+net.load_state_dict(synth.synth_state_dict(4, 0), strict=True); net.eval()
+xyz = synth.synth_cloud('E', 2, 4, 512, 1).cuda()
+net.net.fps_init = synth.fps_inits(2, 512, 1)
+with torch.cuda.stream(pool[{main}]), torch.no_grad():
+    net(xyz)                                        # binds a side stream to THIS caller stream (ev2h_bind_stream)
+    r_main = _lib.side_stream_probe(50)
+pipe = InflightForward(net, depth=2)
+pipe.submit(xyz).result(); pipe.submit(xyz).result(); pipe.drain(); torch.cuda.synchronize()
+mains = [s.cuda_stream for s in pipe.streams]
+r_mains = _lib.streams_concurrent(mains[0], mains[1])
+r_sides = []
+for s in pipe.streams:
+    with torch.cuda.stream(s):
+        r_sides.append(_lib.side_stream_probe(50))
+print('RESULT', r_main, r_mains, r_sides[0], r_sides[1], pipe.binding)
+"""
+
+
+@pytest.mark.parametrize("main", [0, 5])
+def test_side_streams_are_bound_by_measurement_in_a_hostile_host(tmp_path, main):
+    """[r6] ev2h_bind_stream / _lib.concurrent_streams: which hardware queue a HIP stream gets depends on everything the process
+    created before it, so the library MEASURES -- a host that made and used 48 streams before loading the library, a forward on one
+    of them, then two forwards in flight: every caller stream's side stream must run beside it (probe < 1.5; ~2 = shared queue), and
+    the two slot streams beside each other."""
+    _need_gpu()
+    import subprocess
+    import sys
+    script = tmp_path / "hostile.py"
+    script.write_text(_HOSTILE_HOST.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), main=main))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]
+    print(line)
+    vals = [float(v) for v in line.split()[1:5]]
+    assert all(0.6 < v < 1.5 for v in vals), line
 
 
 @pytest.mark.parametrize("log2_spread", [6.0, 6.5, 7.0, 7.5])
