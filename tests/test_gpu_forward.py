@@ -12,7 +12,7 @@ import torch
 from ev2hands_amd import synth
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_", "trained2_")))
 # reference-run fixtures on checkpoints that came out of the reference's own training loop (oracle/make_golden_trained.py)
 TRAINED = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "trained_*.npz")) if "weights" not in os.path.basename(p))
 # [r6] ... and of a SECOND, independent training run (other start, seed, clouds, schedule and loss weighting; tests/trained_ckpt.py: RUNS)
@@ -248,7 +248,10 @@ def test_f16_mode_on_trained_weights_is_bounded(path):
           + "\n   bf16: " + ", ".join(f"{k} {v:.4g}" for k, v in b.items()))
     agree, lerr, mp, mpr, prm = F16_BOUNDS[kind]
     assert m["argmax"] >= agree and m["logits"] <= lerr and m["mpjpe_mm"] <= mp and m["rr_mpjpe_mm"] <= mpr and m["params"] <= prm, m
-    assert m["logits"] < 0.5 * b["logits"] and m["mpjpe_mm"] < 0.5 * b["mpjpe_mm"] and m["argmax"] >= b["argmax"], (m, b)      # 11 mantissa bits against 8
+    # 11 mantissa bits against 8.  (Not asserted fixture by fixture: the ABSOLUTE MPJPE -- the regressed translation behind a collapsed-variance
+    # BatchNorm, two windows per fixture -- is a noisy sample: on trained2_E the two windows give 2.1 mm (f16) against 1.7 mm (bf16) where the same
+    # checkpoint at 32 windows gives 4.4 against 68.5, profiles/r6_trained_precision_report.txt.)
+    assert m["logits"] < 0.5 * b["logits"] and m["rr_mpjpe_mm"] < 0.5 * b["rr_mpjpe_mm"] and m["params"] < 0.5 * b["params"] and m["argmax"] >= b["argmax"], (m, b)
 
 
 def test_f16_family_masks():

@@ -11,7 +11,7 @@ import torch
 from ev2hands_amd import synth
 from oracle import mano_oracle, tehnet_oracle
 
-CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_weights")))
+CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if not os.path.basename(p).startswith(("events_", "metrics_", "rodrigues_", "trained_weights", "trained2_weights")))
 
 
 def rel(a, b):
