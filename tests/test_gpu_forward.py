@@ -202,16 +202,20 @@ def test_bf16_mode_on_trained_weights(path):
 # the optimiser-made checkpoints, against the outputs the REFERENCE recorded (tests/golden/trained_*.npz; two windows each, the worse
 # hand), per fixture kind: (argmax agreement >=, logits rel <=, MPJPE mm <=, root-relative MPJPE mm <=, params rel <=).
 # Measured (this test's printout, profiles/r6_gpu_tests.txt):   f16                                   plain bf16
-#   E_c4_n2048   argmax 1.0000  logits 1.9e-3  MPJPE 12.5 mm  root-relative 0.25 mm  params 1.9e-2 | 0.9963  2.5e-2   71.6   1.97  1.1e-1
-#   E_c4_n8192          0.9995         9.0e-4         0.15                  0.005           3.9e-4 | 0.9946  6.2e-3    0.65  0.02  4.8e-3
-#   E_c5_n2048          0.9988         2.6e-3         7.0                   0.088           4.1e-3 | 0.9888  2.7e-2  271     3.67  2.4e-1
-#   U_c4_n2048          1.0000         1.1e-3        61                     4.6             3.3e-3 | 0.9990  8.3e-3  763    38     5.6e-2
+#   trained_E_c4_n2048    argmax 1.0000  logits 2.5e-3  MPJPE  8.4 mm  root-relative 0.25 mm  params 1.3e-2 | 0.9963  2.5e-2   71.6   1.97  1.1e-1
+#   trained_E_c4_n8192           0.9995         6.1e-4         0.11                  0.003           7.7e-4 | 0.9946  6.2e-3    0.65  0.02  4.8e-3
+#   trained_E_c5_n2048           0.9985         4.1e-3        30.4                   0.39            2.2e-2 | 0.9888  2.7e-2  271     3.67  2.4e-1
+#   trained_U_c4_n2048           1.0000         1.1e-3        63                     6.2             5.5e-3 | 0.9990  8.3e-3  763    38     5.6e-2
+#   trained2_E_c4_n2048          0.9998         3.8e-4         2.1                   0.043           7.7e-3 | 0.9954  2.4e-3    1.7   0.12  2.6e-2
+#   trained2_U_c4_n2048          0.9990         7.3e-4         9.6                   0.70            1.8e-3 | 0.9961  6.5e-3  289     9.9   3.1e-2
+# (two windows per fixture: the absolute MPJPE moved 7 -> 30 mm on E_c5 between two builds of the same arithmetic whose 32-window
+#  figures are 5.0 and 5.9 mm, profiles/r6_trained_precision_report.txt.)
 # The bounds are 2.5-3 x the measured worst.  Root-relative MPJPE is the reference's own metric (evaluate_ev2hands_r.py:43-54); the
 # absolute figure is dominated by the regressed TRANSLATION, which passes through the regression head's Linear -> ReLU -> BatchNorm
 # with collapsed running variances (fold scale 316, DESIGN.md "trained checkpoints") -- any upstream rounding is amplified there, in
 # every mode, in proportion to its size (f16x2: 0.001-0.04 mm).  E = event-like clouds (what the network was trained on); U = uniform
 # clouds, far outside its training distribution (one class everywhere, poses at the edge of the regressor's range): the looser row.
-F16_BOUNDS = {"E": (0.998, 6e-3, 32.0, 0.7, 5e-2), "U": (0.9995, 4e-3, 170.0, 13.0, 1.5e-2)}
+F16_BOUNDS = {"E": (0.997, 1e-2, 80.0, 1.0, 5.5e-2), "U": (0.998, 4e-3, 170.0, 16.0, 1.5e-2)}
 
 
 def _reduced_mode_metrics(path, precision):
