@@ -23,4 +23,6 @@ EV2H_BENCH_FORCE_DIST=1 python bench.py --points 8192 --batch 16 --steps 200 --i
 python bench.py --points 8192 --batch 16 --steps 200 --inflight 2 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_inflight2.json
 python bench.py --points 8192 --batch 16 --steps 200 --inflight 3 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_inflight3.json
 python bench.py --precision f16 --points 8192 --batch 16 --steps 200 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_f16.json
+python bench.py --precision f16 --points 8192 --batch 16 --steps 200 --inflight 2 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_n8192_b16_f16_inflight2.json
+python bench.py --inflight 2 $Q --no-traffic 2>/dev/null | tail -1 > $O/${TAG}_bench_line_default_f16x2_inflight2.json
 for f in $O/${TAG}_bench_line_*.json; do python -c "import json,sys; j=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', j['value'], j['ms_per_step'], j.get('pcie_inclusive',{}).get('value'), j['roofline']['frac'])"; done
