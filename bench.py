@@ -222,12 +222,19 @@ SURVEY_FUSED_BYTES_PER_WINDOW = 16.5e6
 SURVEY_UNFUSED_BYTES_PER_WINDOW = 1.99e9
 
 
-def committed_pmc_traffic(precision="f32"):
+def committed_pmc_traffic(precision="f32", B=256, N=2048):
     """Fallback: ({"kernel": bytes per launch of the profiled kernel, "step": bytes per forward step or None}, source file) from
-    the newest committed rocprofv3 PMC summary (profiles/r*_pmc_hbm_traffic_<mode>*.json, tools/pmc_traffic.py)."""
+    the newest committed rocprofv3 PMC summary (profiles/r*_pmc_hbm_traffic_<mode>*.json, tools/pmc_traffic.py) OF THIS WORKLOAD:
+    tools/profile_round.sh profiles 256 windows of 2048 points, tools/profile_n8192.sh 128 windows of 8192 (`..._n8192_<mode>.json`).
+    Any other shape has no committed figure (None): a 16-window line once carried the 256-window step's 6.4 GB."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_*.json")) +
-                   glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}.json")))
+    if (B, N) == (256, 2048):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}_v*.json")) +
+                       glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{precision}.json")))
+    elif (B, N) == (128, 8192):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_n8192_{precision}.json")))
+    else:
+        files = []
     if not files:
         return None, None
     try:
@@ -348,7 +355,7 @@ def expected_line_keys(world, a):
     return sorted(keys)
 
 
-def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None, site=None):
+def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None, site=None, n_points=2048):
     """Dominant-kernel roofline: algorithmic fp32 FLOPs of the layer (2 x MACs) over the HIP-event duration, against the dense peak of
     the matrix pipe the mode uses; the plane products the split modes execute are reported separately."""
     kavg = sum(kernel_ms_list) / max(len(kernel_ms_list), 1)
@@ -358,8 +365,8 @@ def roofline_entry(precision, B, kernel_ms_list, traffic=None, traffic_src=None,
     alg_flops = 2.0 * site["mac_per_window"] * B
     alg = alg_flops / (kavg * 1e-3) / 1e12 if kavg > 0 else 0.0
     if traffic is None and site["tag"] == PROFILED_TAG:
-        t, src = committed_pmc_traffic(precision if precision != "f16" else "bf16")      # (f16: bf16's images and tile walk; its own profile when committed)
-        t16, src16 = committed_pmc_traffic(precision) if precision == "f16" else (None, None)
+        t, src = committed_pmc_traffic(precision if precision != "f16" else "bf16", B, n_points)      # (f16: bf16's images and tile walk; its own profile when committed)
+        t16, src16 = committed_pmc_traffic(precision, B, n_points) if precision == "f16" else (None, None)
         if t16 is not None:
             t, src = t16, src16
         if t is not None:
@@ -846,7 +853,7 @@ def run_rank(a) -> int:
                 except Exception as e:  # noqa: BLE001 -- never lose the throughput line to the profiler
                     live_src = f"live PMC passes failed ({type(e).__name__}: {str(e)[:200]})"
             if live is None:
-                t, src = committed_pmc_traffic(a.precision)
+                t, src = committed_pmc_traffic(a.precision, B, N)
                 if t is not None:
                     live, live_src = t, (live_src + "; " if live_src else "") + f"committed profile profiles/{src} (not measured in this run)"
             res["ms_per_step_per_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
@@ -859,19 +866,19 @@ def run_rank(a) -> int:
                     res["config"]["rccl_version"] = None
             live_is_site1 = bool(live) and ("kernel_launches_sampled" in live or site1["tag"] == PROFILED_TAG)
             res["roofline"] = roofline_entry(a.precision, B, main_kernel_ms, live["kernel"] if live_is_site1 else None,
-                                             live_src if live_is_site1 else None, site=site1)
+                                             live_src if live_is_site1 else None, site=site1, n_points=N)
             if second_kernel_ms:
                 t2 = live["sites"][site2["tag"]]["bytes"] if live and "sites" in live and site2["tag"] in live["sites"] else None
-                res["roofline_second"] = roofline_entry(a.precision, B, second_kernel_ms, t2, live_src if t2 is not None else None, site=site2)
+                res["roofline_second"] = roofline_entry(a.precision, B, second_kernel_ms, t2, live_src if t2 is not None else None, site=site2, n_points=N)
             res["hbm"] = hbm_entry(B, N, dt / a.steps * 1e3, live.get("step") if live else None, live_src)
             f32_leg = legs.pop("f32", None)
             if f32_leg:
                 res["f32_mfma_leg"] = f32_leg
-                res["roofline_f32"] = roofline_entry("f32", B, leg_kernel_ms["f32"])
+                res["roofline_f32"] = roofline_entry("f32", B, leg_kernel_ms["f32"], n_points=N)
             if "bf16" in legs:                  # BASELINE.json config 3 names this arithmetic: its own roofline entry
-                res["roofline_bf16"] = roofline_entry("bf16", B, leg_kernel_ms["bf16"])
+                res["roofline_bf16"] = roofline_entry("bf16", B, leg_kernel_ms["bf16"], n_points=N)
             if "f16" in legs:                   # [r6] the reduced-precision mode that holds on a trained checkpoint (config 3 in practice)
-                res["roofline_f16"] = roofline_entry("f16", B, leg_kernel_ms["f16"])
+                res["roofline_f16"] = roofline_entry("f16", B, leg_kernel_ms["f16"], n_points=N)
             if legs:
                 res["other_modes"] = legs
             if latency:
