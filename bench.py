@@ -48,7 +48,7 @@ DTYPE = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
                   "on the f16 MFMA, f32 accumulate)",
          "bf16": "bf16 (f32 accumulate)",
          "f16": "f16 (ONE fp16 plane per operand with f16x2's per-window power-of-two range scaling, 1 product per MAC on the f16 MFMA, "
-                "f32 accumulate; layer 1 of the raw-cloud set abstractions in f16x2's three plane products)"}
+                "f32 accumulate)"}
 # algorithmic work of the profiled kernel per window: layers 2+3 of enc.sa2 branch 1 (same MLP and group shape as mano.sa1 branch 1;
 # launched before the two-hand stream fork, so its HIP-event duration is free of overlap)
 # (16384 rows x (128*196 + 196*256) MAC; layer 1 is not in this kernel) -- DESIGN.md "Measurement"
