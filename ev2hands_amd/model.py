@@ -212,6 +212,23 @@ class TEHNet(nn.Module):
         RNG (pointnet2_utils.py:75); same draws, same order: enc.sa1, enc.sa2, left.sa1, right.sa1."""
         return [torch.randint(0, hi, (B,), dtype=torch.long) for hi in (N, synth.SA1_NPOINT, N, N)]
 
+    @staticmethod
+    def _inits_to_device(inits, device) -> torch.Tensor:
+        """[4, B] int64 on the device.  Host tensors -- the reference's own case: torch.randint on the CPU generator,
+        pointnet2_utils.py:75 -- go through PINNED memory: an "asynchronous" copy out of pageable memory blocks the host until the
+        runtime has staged it, which put a host synchronisation in front of every forward and took the whole gain of forwards in
+        flight (16 x 8192, two in flight: 7 490 windows/s with a list of host tensors against 10 470 with a device tensor,
+        tools/debug/inflight_graph.py).  The caching host allocator keeps the pinned block alive until the copy has run."""
+        if torch.is_tensor(inits):
+            st = inits.to(torch.long)
+        else:
+            st = torch.stack([t.to(torch.long) for t in inits])
+        if st.device.type == "cpu":
+            pin = torch.empty(st.shape, dtype=torch.long, pin_memory=True)
+            pin.copy_(st)
+            return pin.to(device, non_blocking=True)
+        return st.to(device, non_blocking=True).contiguous()
+
     def _check_input(self, xyz):
         if self.training:
             raise NotImplementedError("ev2hands_amd implements the inference forward (net.eval()) only")
@@ -415,7 +432,7 @@ class TEHNet(nn.Module):
         self.fps_init = None
         if self.precision == "auto":
             self._auto_decide(xyz, mano_hands, inits)
-        init_dev = torch.stack([t.to(torch.long) for t in inits]).to(device, non_blocking=True).contiguous()
+        init_dev = self._inits_to_device(inits, device)
         res = self._enqueue(x, init_dev, mano_hands, rows=rows, ws=ws)
         for side in ("left", "right"):
             res[side]["faces"] = self._tiled_faces(mano_hands[side], B)          # eval only (TEHNet.py:109-110)
