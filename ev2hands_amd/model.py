@@ -530,10 +530,10 @@ class CapturedForward:
             if tuple(xyz.shape) != tuple(self.x.shape):
                 raise RuntimeError(f"captured for input {tuple(self.x.shape)}, got {tuple(xyz.shape)}")
             self.x.copy_(xyz, non_blocking=True)
-        if fps_init is not None:
-            self.init.copy_(torch.stack([t.to(torch.long) for t in fps_init]), non_blocking=True)
+        if fps_init is not None:                              # (host tensors go through pinned memory: TEHNet._inits_to_device)
+            self.init.copy_(TEHNet._inits_to_device(fps_init, self.init.device), non_blocking=True)
         elif xyz is not None:
-            self.init.copy_(torch.stack(self.net.draw_fps_init(self.B, self.N)), non_blocking=True)     # reference RNG order
+            self.init.copy_(TEHNet._inits_to_device(self.net.draw_fps_init(self.B, self.N), self.init.device), non_blocking=True)     # reference RNG order
         self.graph.replay()
         if self.net.mhlnes and xyz is not None:
             xyz[:, 2].copy_(self.x[:, 2])                     # the in-place overwrite of TEHNet.py:176-177 reaches the caller's tensor
