@@ -99,6 +99,7 @@ struct SideCtx {
     void* owner = nullptr;       // the caller's stream this side stream serves (slot 0: the first caller's, claimed at its first forward)
     bool claimed = false;
     bool bound = false;          // ev2h_bind_stream has measured this pair (and replaced the stream if it shared the caller's hardware queue)
+    unsigned long long last_use = 0;      // g_side_tick of the last forward / probe that looked this slot up (recycling, see side_ctx)
 };
 constexpr int EV2H_MAX_DEVICES = 16;
 // [r6] One side stream PER CALLER STREAM (up to EV2H_SIDE_SLOTS per host thread and device): forwards that are in flight at the same
@@ -109,6 +110,7 @@ constexpr int EV2H_MAX_DEVICES = 16;
 constexpr int EV2H_SIDE_SLOTS = 4;
 static thread_local SideCtx g_side[EV2H_MAX_DEVICES][EV2H_SIDE_SLOTS];
 
+static thread_local unsigned long long g_side_tick = 0;
 static thread_local bool g_side_claim = false;      // set by ev2h_forward / the probe around side_ctx(): this call binds a slot to its caller stream
 static inline bool caller_stream_claims(void*) { return g_side_claim; }
 static thread_local int g_side_disabled = 0;      // ev2h_set_side_stream(0): run everything on the caller's stream (per host thread)
@@ -124,16 +126,28 @@ static SideCtx* side_ctx(void* caller_stream) {     // the side stream that serv
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EV2H_MAX_DEVICES) return nullptr;
     int slot = 0;
     if (caller_stream || g_side[dev][0].claimed) {
-        // the slot that already serves this caller stream, else the first free one; all taken: share slot 0 (correct, only serialised)
-        int found = -1, free_ = -1;
+        // the slot that already serves this caller stream, else the first free one; all taken: the slot that has not been looked up
+        // for the longest time is RECYCLED if it has been idle for a while (a host that keeps making new streams -- one
+        // InflightForward per request, torch's pool handing out other handles -- would otherwise be stuck with its first four
+        // forever), else slot 0 is shared (correct, only serialised: more than four streams in rotation must not evict each other --
+        // every eviction costs a probe).  Handing a side stream to a new owner is safe whatever it is still running: each forward
+        // forks it by an event wait and joins it by an event before it returns, and the enqueue calls of one host thread do not interleave.
+        int found = -1, free_ = -1, lru = 0;
         for (int i = 0; i < EV2H_SIDE_SLOTS; ++i) {
             if (g_side[dev][i].claimed && g_side[dev][i].owner == caller_stream) { found = i; break; }
             if (!g_side[dev][i].claimed && free_ < 0) free_ = i;
+            if (g_side[dev][i].last_use < g_side[dev][lru].last_use) lru = i;
         }
         slot = found >= 0 ? found : (free_ >= 0 ? free_ : 0);
+        if (found < 0 && free_ < 0 && caller_stream_claims(caller_stream) && g_side_tick - g_side[dev][lru].last_use >= 16) {
+            slot = lru;
+            g_side[dev][slot].claimed = false;          // re-claimed just below, for the new owner; measured again by ev2h_bind_stream
+            g_side[dev][slot].bound = false;
+        }
     }
     SideCtx& c = g_side[dev][slot];
     if (caller_stream_claims(caller_stream) && !c.claimed) { c.claimed = true; c.owner = caller_stream; }
+    if (caller_stream_claims(caller_stream) && c.claimed && c.owner == caller_stream) c.last_use = ++g_side_tick;
     side_open(c);
     return c.state == 1 ? &c : nullptr;
 }

@@ -115,7 +115,8 @@ int ev2h_streams_concurrent(ev2h_stream_t a, ev2h_stream_t b, int spin_us, float
  * stream of its own.  This call MEASURES: it probes the slot's side stream against `stream` and against every stream the calling
  * thread has bound before (ev2h_streams_concurrent), and while a pair is serialised creates another candidate (at most 8) and keeps
  * the best; rejected candidates are destroyed.  Synchronises `stream` (~1-5 ms, once); does nothing while `stream` is capturing,
- * in single-stream mode, or when all side-stream slots (4 per host thread and device) serve other streams.
+ * in single-stream mode, or while all side-stream slots (4 per host thread and device) serve other streams that are in use -- such a
+ * stream shares the first slot's side stream (correct, only serialised); a slot that has been idle for eight forwards is recycled.
  * info (optional, int[3]): candidates tried, 1000 x ratio of the chosen pair, number of earlier-bound streams it still shares a queue with. */
 int ev2h_bind_stream(ev2h_stream_t stream, int* info);
 /* [ABI 8] What shader clock is the chip running at RIGHT NOW?  Enqueues a one-wave kernel on `stream` that sleeps for ~spin_us
