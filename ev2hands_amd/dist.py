@@ -218,7 +218,8 @@ class GatherPipeline:
     def __init__(self, N: int, global_batch: int, device, group=None, depth: int = 2, n_pose: int = synth.MANO_CMPS, inflight: int = 0, net=None):
         """inflight = K > 1 (with net = the TEHNetWrapper): `forward(xyz)` is then ONE call per step -- forward i runs on slot stream
         i mod K with its own workspace (ev2hands_amd/inflight.py: a rank's share can be too small to fill its GPU; 16 windows of 8192
-        points: +20 % with two in flight), writes into gather buffer i mod depth and the asynchronous all-gather is issued from
+        points: +35 % with two in flight, also inside the RCCL process -- the slot streams and their side streams are bound to hardware
+        queues by measurement, _lib.concurrent_streams / ev2h_bind_stream), writes into gather buffer i mod depth and the asynchronous all-gather is issued from
         the SLOT'S stream right behind it, so that the caller's stream never waits for a forward.  The reference's analogue is the one
         `net(lnes)` call under nn.DataParallel (train.py:68,83).  depth is raised to K (two forwards in flight never share a buffer)."""
         if depth < 1:

@@ -5,8 +5,10 @@ latency-bound for a fifth of its time: farthest point sampling is 512 DEPENDENT 
 windows there are), followed by selection kernels that are chains of L2 round trips.  Consecutive batches are independent
 (eval-mode windows share nothing, /root/reference/src/Ev2Hands/model/TEHNet.py:168-197), so the head of batch i + 1 can run
 under the matrix-pipe-bound tail of batch i: `InflightForward` issues forward i on stream i mod depth with its own workspace.
-16 windows of 8192 points: 7 090 -> 8 560 windows/s with depth 2 (profiles/r5_inflight.txt); at 128 windows per GPU the
-chip is already full (+2.5 %), at the headline shape (256 windows of 2048 points) it is neutral -- the default is one in flight.
+16 windows of 8192 points: 7 500 -> 10 300-10 500 windows/s with depth 2 (round 6, profiles/r6_inflight.txt,
+profiles/r6_side_streams_by_measurement.txt; round 5: 7 090 -> 8 560), 8 windows of 2048 points: 7 200 -> 11 160; depth 3
+over-subscribes the four hardware queues a process gets (9 000); at 128 windows per GPU the chip is already full (+2.5 %), at the
+headline shape (256 windows of 2048 points) +2 % -- the default is one in flight.
 
 Numbers are unchanged by construction: the same ev2h_forward with the same arguments, only on another stream
 (tests/test_gpu_forward.py::test_inflight_forwards_are_bit_identical).
