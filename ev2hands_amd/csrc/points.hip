@@ -426,7 +426,8 @@ int ev2h_fps_multi_chunk(const float* pts4, int B, int N, int njobs, const int* 
     else if (N <= 2048) fps_kernel<8><<<grid, 256, lds, st>>>(p, N, jobs);
     // N > 2048: the staged points (64 / 128 KB) leave two / one workgroup per CU, and with 16 / 32 points per thread the distance update
     // is most of a sampling step -- eight waves per window halve it (N = 2048 keeps four: there the exchange and the barrier dominate
-    // and sixteen waves measured slower).  Same maxima, same tie-break: identical indices.
+    // and sixteen waves measured slower; sixteen waves at 8192 points [r6]: 16 x 8192 7 135 against 7 515 windows/s,
+    // profiles/r6_ab_fps1024_refuted.txt).  Same maxima, same tie-break: identical indices.
     else if (N <= 4096) fps_kernel<8, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
     else if (N <= 8192) fps_kernel<16, 512, true><<<grid, 512, lds, st>>>(p, N, jobs);
     else if (N <= 16384) fps_kernel<16, 1024, false><<<grid, 1024, 0, st>>>(p, N, jobs);      // beyond the LDS-resident sizes
